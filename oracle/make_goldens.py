@@ -1,0 +1,196 @@
+"""Generate golden fixtures by importing the REFERENCE in the build container.
+
+TEST INFRASTRUCTURE ONLY (see oracle/hiera_oracle.py header).  Run once, here:
+
+    python oracle/make_goldens.py            # writes tests/golden/*.npz
+
+The reference checkout (/root/reference) never travels to the GPU box and no
+reference source is copied: this script only *imports and runs* it, on weights
+and frames produced by this repo's own seeded generator
+(image_segmentation_amd/synth.py), and stores inputs-free OUTPUT vectors.  The
+GPU box regenerates the same weights/frames from the seed.
+
+Import recipe: two arithmetic-free stub modules satisfy
+import-time dependencies that are absent offline -- ``hydra`` (only queried by
+sam2/__init__.py:7-11) and ``iopath`` (only touched when Hiera(weights_path=..)
+is set, hieradet.py:268-271).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("LSAM_REFERENCE", "/root/reference")
+sys.path.insert(0, REPO)
+
+from image_segmentation_amd.synth import fill_synthetic_, synth_frames, synth_tensor  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+
+TINY = dict(embed_dim=56, num_heads=1, stages=(2, 2, 3, 3), global_att_blocks=(5,))
+BPLUS = dict(embed_dim=112, num_heads=2)  # sam2_model.py:12
+
+
+def import_reference():
+    hydra = types.ModuleType("hydra")
+    hydra.__path__ = []
+    core = types.ModuleType("hydra.core")
+    core.__path__ = []
+    gh = types.ModuleType("hydra.core.global_hydra")
+
+    class GlobalHydra:
+        @staticmethod
+        def instance():
+            return GlobalHydra()
+
+        def is_initialized(self):
+            return True
+
+    gh.GlobalHydra = GlobalHydra
+    hydra.initialize_config_module = lambda *a, **k: None
+    sys.modules.update({"hydra": hydra, "hydra.core": core, "hydra.core.global_hydra": gh})
+    iopath = types.ModuleType("iopath")
+    iopath.__path__ = []
+    common = types.ModuleType("iopath.common")
+    common.__path__ = []
+    fio = types.ModuleType("iopath.common.file_io")
+    fio.g_pathmgr = None
+    sys.modules.update({"iopath": iopath, "iopath.common": common, "iopath.common.file_io": fio})
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(REF, "SAM2", "sam2"))
+    from SAM2.sam2.sam2.modeling.backbones.hieradet import Hiera, MultiScaleBlock
+    from SAM2.sam2.sam2.modeling.backbones.image_encoder import FpnNeck, ImageEncoder
+    from SAM2.sam2.sam2.modeling.position_encoding import PositionEmbeddingSine
+    import lora_qkv
+    return dict(Hiera=Hiera, MultiScaleBlock=MultiScaleBlock, FpnNeck=FpnNeck,
+                ImageEncoder=ImageEncoder, PositionEmbeddingSine=PositionEmbeddingSine,
+                lora_qkv=lora_qkv)
+
+
+def build_reference_encoder(R, hiera_kwargs, rank, seed):
+    trunk = R["Hiera"](**hiera_kwargs)
+    pe = R["PositionEmbeddingSine"](num_pos_feats=256, normalize=True, temperature=10000)
+    neck = R["FpnNeck"](position_encoding=pe, d_model=256,
+                        backbone_channel_list=list(trunk.channel_list),
+                        fpn_top_down_levels=[2, 3], fpn_interp_model="nearest")
+    enc = R["ImageEncoder"](trunk=trunk, neck=neck, scalp=1)
+    fill_synthetic_(enc, seed)          # "checkpoint load" happens before wrapping
+    holder = types.SimpleNamespace(image_encoder=enc)
+    for p in enc.parameters():
+        p.requires_grad = False
+    R["lora_qkv"].wrap_image_encoder_lora(holder, rank)
+    with torch.no_grad():               # non-zero B so dA != 0
+        for name, p in enc.named_parameters():
+            if "linear_a_" in name or "linear_b_" in name:
+                p.copy_(synth_tensor(name, tuple(p.shape), seed))
+    return enc
+
+
+def stats(t: torch.Tensor):
+    t = t.detach().double()
+    return np.array([t.mean().item(), t.std().item(), t.norm().item()], dtype=np.float64)
+
+
+def lora_grads(enc):
+    out = {}
+    for name, p in enc.named_parameters():
+        if p.requires_grad:
+            out["grad." + name] = p.grad.detach().numpy().copy()
+    return out
+
+
+def run(R, hiera_kwargs, rank, seed, n, size, tag, full):
+    torch.manual_seed(0)
+    enc = build_reference_encoder(R, hiera_kwargs, rank, seed)
+    img = synth_frames(n, size, seed)
+    block_outs = []
+    hooks = [b.register_forward_hook(lambda m, i, o: block_outs.append(o.detach()))
+             for b in enc.trunk.blocks]
+    out = enc(img)
+    for h in hooks:
+        h.remove()
+    loss = sum((f.float() ** 2).mean() for f in out["backbone_fpn"])
+    loss.backward()
+    g = {"loss": np.array(loss.item(), dtype=np.float64)}
+    g.update(lora_grads(enc))
+    for i, f in enumerate(out["backbone_fpn"]):
+        g[f"fpn{i}.stats"] = stats(f)
+    for i, b in enumerate(block_outs):
+        g[f"block{i}.stats"] = stats(b)
+    if full:
+        for i, b in enumerate(block_outs):
+            g[f"block{i}.sub"] = b[:, ::4, ::4, ::2].numpy().copy()
+        g["fpn2"] = out["backbone_fpn"][2].detach().numpy().copy()
+        g["fpn1.sub"] = out["backbone_fpn"][1].detach()[:, ::4, ::2, ::2].numpy().copy()
+        g["fpn0.sub"] = out["backbone_fpn"][0].detach()[:, ::8, ::4, ::4].numpy().copy()
+        g["pos2"] = out["vision_pos_enc"][2][:1].detach().numpy().copy()
+    else:
+        g["fpn2.sub"] = out["backbone_fpn"][2].detach()[:, ::8, ::4, ::4].numpy().copy()
+        g["stage3.sub"] = block_outs[-1][:, ::4, ::4, ::16].numpy().copy()
+    path = os.path.join(GOLD, tag + ".npz")
+    np.savez_compressed(path, **g)
+    print(f"wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB, loss {loss.item():.6f}")
+
+
+def micro_lora_slice(R):
+    """LoRA slice rule with dim != dim_out (lora_qkv.py:99,106-107): the adds go
+    to the first/last in_features columns, which are NOT the q and v thirds."""
+    torch.manual_seed(0)
+    lq = R["lora_qkv"]
+    d, dout, r = 64, 96, 4
+    qkv = torch.nn.Linear(d, 3 * dout)
+    mods = [torch.nn.Linear(d, r, bias=False), torch.nn.Linear(r, d, bias=False),
+            torch.nn.Linear(d, r, bias=False), torch.nn.Linear(r, d, bias=False)]
+    m = lq.LoRA_qkv(qkv, *mods)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            p.copy_(synth_tensor("micro." + name, tuple(p.shape), 3))
+    x = torch.randn(3, 5, 7, d, generator=torch.Generator().manual_seed(11))
+    y = m(x)
+    path = os.path.join(GOLD, "micro_lora_slice.npz")
+    np.savez_compressed(path, y=y.detach().numpy())
+    print("wrote", path)
+
+
+def micro_blocks(R):
+    """Single MultiScaleBlock goldens: (a) ws=14 on a 16x16 map (pad to 28),
+    (b) q-pool + pad transition (ws=14, stride 2, 16x16 -> 8x8), (c) global."""
+    cases = {
+        "pad": dict(dim=112, dim_out=112, num_heads=2, window_size=14, q_stride=None),
+        "poolpad": dict(dim=112, dim_out=224, num_heads=4, window_size=14, q_stride=(2, 2)),
+        "pool8": dict(dim=56, dim_out=112, num_heads=2, window_size=8, q_stride=(2, 2)),
+        "global": dict(dim=112, dim_out=112, num_heads=2, window_size=0, q_stride=None),
+        "ws7pad": dict(dim=224, dim_out=224, num_heads=4, window_size=7, q_stride=None),
+    }
+    g = {}
+    for tag, kw in cases.items():
+        blk = R["MultiScaleBlock"](**kw)
+        with torch.no_grad():
+            for name, p in blk.named_parameters():
+                p.copy_(synth_tensor(f"micro.{tag}." + name, tuple(p.shape), 5))
+        hw = 18 if tag == "ws7pad" else 16
+        x = torch.randn(2, hw, hw, kw["dim"], generator=torch.Generator().manual_seed(7))
+        with torch.no_grad():
+            g[tag] = blk(x).numpy().copy()
+    path = os.path.join(GOLD, "micro_blocks.npz")
+    np.savez_compressed(path, **g)
+    print("wrote", path)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    R = import_reference()
+    micro_lora_slice(R)
+    micro_blocks(R)
+    run(R, TINY, rank=4, seed=0, n=2, size=256, tag="tiny_r4", full=True)
+    run(R, BPLUS, rank=4, seed=0, n=1, size=1024, tag="bplus_r4_1024", full=False)
+
+
+if __name__ == "__main__":
+    main()
