@@ -1,0 +1,488 @@
+// Windowed / global multi-head attention for Hiera, forward (MFMA, flash-style) and the
+// LoRA-block backward.
+//
+// The kernels read the qkv GEMM output in its natural [N,H,W,3*nh*hd] layout and write the
+// un-partitioned, cropped [N,H',W',nh*hd] result, so the reference's window_partition /
+// window_unpartition / do_pool copies (backbones/utils.py:16-60, hieradet.py:25-36) never
+// materialise.  Semantics that are easy to lose:
+//  * zero-pad tokens are created AFTER LN1 and BEFORE qkv, so their q/k/v equal the qkv bias and
+//    they take part as keys/values in the un-masked softmax (hieradet.py:136,146,70-74);
+//  * q-pooling is a 2x2 max over q only, inside each window (hieradet.py:64-67);
+//  * only real (un-cropped) query positions are computed.
+//
+// Forward dataflow per workgroup = one (window, head, query block):  K/V tiles of 32 keys are
+// staged to LDS (K row-major XOR-swizzled; V transposed).  S^T = K.Q^T is formed with the key on
+// the MFMA row index, so each lane owns ONE query (column l&15) and 8 keys per tile: softmax
+// needs only two xor-shuffles per tile, and the probabilities are already the B-operand fragment
+// of O^T = V^T.P^T (k-slot 8g+j  <->  key 4g+j for j<4, 16+4g+(j-4) otherwise).
+#include "kernels.hpp"
+
+namespace lsam {
+
+constexpr int KT = 32;  // keys per tile
+
+template <typename T> struct VtLayout;  // transposed V tile: [d][32 keys] + pad
+template <> struct VtLayout<bf16> { static constexpr int RB = 72; };
+template <> struct VtLayout<float> { static constexpr int RB = 144; };
+
+template <typename T> __device__ __forceinline__ void load8f(const T* p, float* v);
+template <> __device__ __forceinline__ void load8f<bf16>(const bf16* p, float* v) {
+    const bf16x8 x = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)x[j];
+}
+template <> __device__ __forceinline__ void load8f<float>(const float* p, float* v) {
+    const f32x4 a = load4(p), b = load4(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+}
+template <typename T> __device__ __forceinline__ typename Tr<T>::frag frag_from_f(const float* v) {
+    typename Tr<T>::frag f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = from_f<T>(v[j]);
+    return f;
+}
+
+struct WinGeom {
+    int wsh, wsw, nwy, nwx;   // window size (rows, cols) on the input grid, windows per image
+    int qh, qw, Ho, Wo;       // query window size and output grid
+};
+__host__ __device__ inline WinGeom make_geom(int H, int W, int ws, int pool) {
+    WinGeom g;
+    g.wsh = ws > 0 ? ws : H;
+    g.wsw = ws > 0 ? ws : W;
+    g.nwy = (H + g.wsh - 1) / g.wsh;
+    g.nwx = (W + g.wsw - 1) / g.wsw;
+    g.qh = g.wsh / pool;
+    g.qw = g.wsw / pool;
+    g.Ho = H / pool;
+    g.Wo = W / pool;
+    return g;
+}
+
+template <typename T, int QT, int HDP>
+__global__ void attn_fwd_kernel(const AttnArgs p, const float c_log2) {
+    constexpr int EPC = Tr<T>::EPC, CPF = Tr<T>::CPF;
+    constexpr int KSD = HDP / 32, DT = HDP / 16;
+    constexpr int RB = HDP * (int)sizeof(T), CPR = RB / 16;  // K tile row bytes / chunks
+    constexpr int VRB = VtLayout<T>::RB;
+    using frag = typename Tr<T>::frag;
+
+    __shared__ __attribute__((aligned(16))) char ks_[KT * RB];
+    __shared__ __attribute__((aligned(16))) char vt_[HDP * VRB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+    const int g = lane >> 4, lr = lane & 15;
+    const int H = p.H, W = p.W, nh = p.nh, hd = p.hd, dout = nh * hd;
+    const WinGeom G = make_geom(H, W, p.ws, p.pool);
+    const int h = blockIdx.y;
+    const int win = blockIdx.x % (G.nwy * G.nwx), n = blockIdx.x / (G.nwy * G.nwx);
+    const int wy = win / G.nwx, wx = win % G.nwx;
+    const int rh = min(G.qh, G.Ho - wy * G.qh), rw = min(G.qw, G.Wo - wx * G.qw);
+    const int nq = rh * rw, nk = G.wsh * G.wsw;
+    const int qblock = (blockDim.x >> 6) * QT * 16;
+    const int qbase = blockIdx.z * qblock;
+    if (qbase >= nq) return;  // uniform for the workgroup, before any barrier
+
+    const T* __restrict__ qkv = static_cast<const T*>(p.qkv);
+    const float* __restrict__ bias = p.bias;
+    const size_t img_tok = (size_t)n * H * W;
+
+    // ---- Q fragments (kept in registers for the whole kernel) -------------------------------
+    frag qf[QT][KSD];
+    int qtok[QT];  // output token index or -1
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int qi = qbase + (wave * QT + qt) * 16 + lr;
+        const bool qv = qi < nq;
+        const int iy = qv ? qi / rw : 0, ix = qv ? qi % rw : 0;
+        qtok[qt] = qv ? (int)(((size_t)n * G.Ho + (wy * G.qh + iy)) * G.Wo + (wx * G.qw + ix)) : -1;
+#pragma unroll
+        for (int ks = 0; ks < KSD; ++ks) {
+            const int d0 = ks * 32 + g * 8;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            if (qv && d0 < hd) {
+                if (p.pool == 1) {
+                    const size_t tok = img_tok + (size_t)(wy * G.wsh + iy) * W + (wx * G.wsw + ix);
+                    load8f<T>(qkv + tok * p.ldqkv + h * hd + d0, v);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = -3.0e38f;
+                    for (int a = 0; a < p.pool; ++a)
+                        for (int b = 0; b < p.pool; ++b) {
+                            const int y = wy * G.wsh + iy * p.pool + a, x = wx * G.wsw + ix * p.pool + b;
+                            float t[8];
+                            if (y < H && x < W) {
+                                load8f<T>(qkv + (img_tok + (size_t)y * W + x) * p.ldqkv + h * hd + d0, t);
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) t[j] = to_f(from_f<T>(bias[h * hd + d0 + j]));
+                            }
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], t[j]);
+                        }
+                }
+            }
+            qf[qt][ks] = frag_from_f<T>(v);
+        }
+    }
+
+    f32x4 o[QT][DT];
+    float mrun[QT], lrun[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        mrun[qt] = -1.0e30f;
+        lrun[qt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int ntiles = (nk + KT - 1) / KT;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        __syncthreads();
+        // ---- stage K (row-major, swizzled) and V (transposed) --------------------------------
+        for (int i = tid; i < KT * CPR; i += nthr) {
+            const int key = i / CPR, ch = i % CPR, d0 = ch * EPC;
+            const int kk = tile * KT + key;
+            uint4 kv = make_uint4(0, 0, 0, 0), vv = kv;
+            if (kk < nk && d0 < hd) {
+                const int ky = kk / G.wsw, kx = kk % G.wsw;
+                const int y = wy * G.wsh + ky, x = wx * G.wsw + kx;
+                if (y < H && x < W) {
+                    const T* src = qkv + (img_tok + (size_t)y * W + x) * p.ldqkv + dout + h * hd + d0;
+                    kv = *reinterpret_cast<const uint4*>(src);
+                    vv = *reinterpret_cast<const uint4*>(src + dout);
+                } else {  // zero-pad token: k, v = bias
+                    T kt_[EPC], vt2[EPC];
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        kt_[e] = from_f<T>(bias[dout + h * hd + d0 + e]);
+                        vt2[e] = from_f<T>(bias[2 * dout + h * hd + d0 + e]);
+                    }
+                    kv = *reinterpret_cast<const uint4*>(kt_);
+                    vv = *reinterpret_cast<const uint4*>(vt2);
+                }
+            }
+            *reinterpret_cast<uint4*>(ks_ + key * RB + (swz(key, ch) << 4)) = kv;
+            const T* ve = reinterpret_cast<const T*>(&vv);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e)
+                *reinterpret_cast<T*>(vt_ + (d0 + e) * VRB + key * (int)sizeof(T)) = ve[e];
+        }
+        __syncthreads();
+
+        // ---- S^T = K . Q^T ---------------------------------------------------------------------
+        frag kf[2][KSD];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < KSD; ++ks) {
+                const int row = t * 16 + lr, c0 = (ks * 4 + g) * CPF;
+                const uint4 x0 = *reinterpret_cast<const uint4*>(ks_ + row * RB + (swz(row, c0) << 4));
+                uint4 x1 = x0;
+                if constexpr (CPF == 2)
+                    x1 = *reinterpret_cast<const uint4*>(ks_ + row * RB + (swz(row, c0 + 1) << 4));
+                kf[t][ks] = make_frag(x0, x1, T{});
+            }
+        frag pf[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            f32x4 s[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KSD; ++ks) mma16(kf[t][ks], qf[qt][ks], s[t]);
+            }
+            float mx = -1.0e30f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kidx = tile * KT + t * 16 + g * 4 + r;
+                    s[t][r] = kidx < nk ? s[t][r] * c_log2 : -1.0e30f;
+                    mx = fmaxf(mx, s[t][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(mrun[qt], mx);
+            const float alpha = exp2f(mrun[qt] - mnew);
+            mrun[qt] = mnew;
+            float pv[8], psum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = exp2f(s[t][r] - mnew);
+                    pv[t * 4 + r] = e;
+                    psum += e;
+                }
+            lrun[qt] = lrun[qt] * alpha + psum;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+            pf[qt] = frag_from_f<T>(pv);
+        }
+        // ---- O^T += V^T . P^T --------------------------------------------------------------------
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const char* vrow = vt_ + (dt * 16 + lr) * VRB;
+            frag vf;
+            if constexpr (sizeof(T) == 2) {
+                const uint2 a = *reinterpret_cast<const uint2*>(vrow + 8 * g);
+                const uint2 b = *reinterpret_cast<const uint2*>(vrow + 32 + 8 * g);
+                vf = __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, b.x, b.y));
+            } else {
+                const uint4 a = *reinterpret_cast<const uint4*>(vrow + 16 * g);
+                const uint4 b = *reinterpret_cast<const uint4*>(vrow + 64 + 16 * g);
+                vf = make_frag(a, b, T{});
+            }
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) mma16(vf, pf[qt], o[qt][dt]);
+        }
+    }
+
+    // ---- normalise and store: lane holds O[q = l&15][d = 16dt + 4g .. +3] ---------------------
+    T* __restrict__ out = static_cast<T*>(p.out);
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float l = lrun[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (qtok[qt] < 0) continue;
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d0 = dt * 16 + g * 4;
+            if (d0 < hd) store4(out + (size_t)qtok[qt] * p.ldo + h * hd + d0, o[qt][dt] * inv);
+        }
+        if (p.lse && g == 0)
+            p.lse[(size_t)qtok[qt] * nh + h] = (mrun[qt] + log2f(l)) * 0.69314718055994531f;
+    }
+}
+
+template <typename T, int QT>
+static int attn_fwd_launch(const AttnArgs& a, int nwaves, int nqb, hipStream_t s) {
+    const WinGeom G = make_geom(a.H, a.W, a.ws, a.pool);
+    const float c = (1.0f / sqrtf((float)a.hd)) * 1.4426950408889634f;
+    const dim3 grid(a.N * G.nwy * G.nwx, a.nh, nqb), blk(64 * nwaves);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, QT, 64>), grid, blk, 0, s, a, c);
+    LSAM_LAUNCH_CHECK();
+    return LSAM_OK;
+}
+
+template <typename T> int launch_attn_fwd(const AttnArgs& a, hipStream_t s) {
+    constexpr int EPC = Tr<T>::EPC;
+    LSAM_REQUIRE(a.qkv && a.bias && a.out, LSAM_ERR_BAD_ARG, "attention: null pointer");
+    LSAM_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.nh > 0 && a.hd > 0, LSAM_ERR_BAD_ARG, "attention: empty shape");
+    LSAM_REQUIRE(a.hd % 8 == 0 && a.hd <= 64, LSAM_ERR_UNSUPPORTED, "attention: head_dim %d (need %%8==0, <=64)", a.hd);
+    LSAM_REQUIRE(a.pool == 1 || a.pool == 2, LSAM_ERR_UNSUPPORTED, "attention: q-pool stride %d", a.pool);
+    LSAM_REQUIRE(a.ws >= 0 && (a.pool == 1 || (a.ws > 0 && a.ws % 2 == 0 && a.H % 2 == 0 && a.W % 2 == 0)),
+                 LSAM_ERR_UNSUPPORTED, "attention: pooled blocks need an even window and grid (ws=%d)", a.ws);
+    LSAM_REQUIRE(a.ldqkv >= 3 * a.nh * a.hd && a.ldqkv % EPC == 0 && a.ldo >= a.nh * a.hd && a.ldo % 4 == 0 &&
+                     aligned16(a.qkv) && aligned16(a.out),
+                 LSAM_ERR_BAD_ARG, "attention: leading dimensions / alignment");
+    LSAM_REQUIRE(a.nh <= 65535, LSAM_ERR_UNSUPPORTED, "attention: too many heads");
+    const WinGeom G = make_geom(a.H, a.W, a.ws, a.pool);
+    const int max_nq = G.qh * G.qw;
+    if (max_nq > 64) {
+        const int nwaves = min(4, cdiv(max_nq, 32));
+        return attn_fwd_launch<T, 2>(a, nwaves, cdiv(max_nq, nwaves * 32), s);
+    }
+    const int nwaves = cdiv(max_nq, 16);
+    return attn_fwd_launch<T, 1>(a, nwaves, 1, s);
+}
+template int launch_attn_fwd<float>(const AttnArgs&, hipStream_t);
+template int launch_attn_fwd<bf16>(const AttnArgs&, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------
+// Backward for the LoRA blocks (un-pooled windows with <= 64 keys).  One workgroup per
+// (window, head); everything lives in LDS in fp32:
+//   P = exp(S*scale - lse), dP = dO V^T, delta_i = sum_j P_ij dP_ij (= rowsum(dO*O)),
+//   dS = P (dP - delta) scale, dQ = dS K, dK = dS^T Q, dV = P^T dO.
+// Every real token belongs to exactly one window, so each dq/dk/dv element is written once.
+// ---------------------------------------------------------------------------------------------
+constexpr int BW_NK = 64;
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdArgs p, const float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int hd = p.hd, LDH = hd + 1, LDP = BW_NK + 1;
+    float* Qs = sm;
+    float* Ks = Qs + BW_NK * LDH;
+    float* Vs = Ks + BW_NK * LDH;
+    float* Ds = Vs + BW_NK * LDH;   // dO
+    float* Ps = Ds + BW_NK * LDH;
+    float* Ss = Ps + BW_NK * LDP;   // dP, then dS
+    float* lse_s = Ss + BW_NK * LDP;
+    float* del_s = lse_s + BW_NK;
+    int* qtok_s = reinterpret_cast<int*>(del_s + BW_NK);
+    int* ktok_s = qtok_s + BW_NK;
+
+    const int tid = threadIdx.x;
+    const int H = p.H, W = p.W, nh = p.nh, dout = nh * hd, ws = p.ws;
+    const int nwy = (H + ws - 1) / ws, nwx = (W + ws - 1) / ws;
+    const int h = blockIdx.y;
+    const int win = blockIdx.x % (nwy * nwx), n = blockIdx.x / (nwy * nwx);
+    const int wy = win / nwx, wx = win % nwx;
+    const int rh = min(ws, H - wy * ws), rw = min(ws, W - wx * ws);
+    const int nq = rh * rw, nk = ws * ws;
+    const T* __restrict__ qkv = static_cast<const T*>(p.qkv);
+    const T* __restrict__ dO = static_cast<const T*>(p.dout);
+    const size_t img_tok = (size_t)n * H * W;
+
+    if (tid < BW_NK) {
+        int qt = -1, kt = -1;
+        if (tid < nq) qt = (int)(img_tok + (size_t)(wy * ws + tid / rw) * W + (wx * ws + tid % rw));
+        if (tid < nk) {
+            const int y = wy * ws + tid / ws, x = wx * ws + tid % ws;
+            if (y < H && x < W) kt = (int)(img_tok + (size_t)y * W + x);
+        }
+        qtok_s[tid] = qt;
+        ktok_s[tid] = kt;
+        lse_s[tid] = qt >= 0 ? p.lse[(size_t)qt * nh + h] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < BW_NK * hd; i += 256) {
+        const int r = i / hd, d = i % hd;
+        const int qt = qtok_s[r], kt = ktok_s[r];
+        float q = 0.f, dv = 0.f, k = 0.f, v = 0.f;
+        if (qt >= 0) {
+            q = to_f(qkv[(size_t)qt * p.ldqkv + h * hd + d]);
+            dv = to_f(dO[(size_t)qt * p.lddo + h * hd + d]);
+        }
+        if (r < nk) {
+            if (kt >= 0) {
+                k = to_f(qkv[(size_t)kt * p.ldqkv + dout + h * hd + d]);
+                v = to_f(qkv[(size_t)kt * p.ldqkv + 2 * dout + h * hd + d]);
+            } else {
+                k = to_f(from_f<T>(p.bias[dout + h * hd + d]));
+                v = to_f(from_f<T>(p.bias[2 * dout + h * hd + d]));
+            }
+        }
+        Qs[r * LDH + d] = q;
+        Ds[r * LDH + d] = dv;
+        Ks[r * LDH + d] = k;
+        Vs[r * LDH + d] = v;
+    }
+    __syncthreads();
+
+    const int ti = tid >> 4, tj = tid & 15;
+    {
+        float s[4][4], dp[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) s[a][b] = dp[a][b] = 0.f;
+        for (int d = 0; d < hd; ++d) {
+            float qa[4], da[4], kb[4], vb[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                qa[a] = Qs[(ti + 16 * a) * LDH + d];
+                da[a] = Ds[(ti + 16 * a) * LDH + d];
+                kb[a] = Ks[(tj + 16 * a) * LDH + d];
+                vb[a] = Vs[(tj + 16 * a) * LDH + d];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    s[a][b] += qa[a] * kb[b];
+                    dp[a][b] += da[a] * vb[b];
+                }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int i = ti + 16 * a, j = tj + 16 * b;
+                const bool ok = i < nq && j < nk;
+                Ps[i * LDP + j] = ok ? __expf(s[a][b] * scale - lse_s[i]) : 0.f;
+                Ss[i * LDP + j] = ok ? dp[a][b] : 0.f;
+            }
+    }
+    __syncthreads();
+    if (tid < BW_NK) {
+        float dl = 0.f;
+        for (int j = 0; j < BW_NK; ++j) dl += Ps[tid * LDP + j] * Ss[tid * LDP + j];
+        del_s[tid] = dl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = ti + 16 * a, j = tj + 16 * b;
+            Ss[i * LDP + j] = Ps[i * LDP + j] * (Ss[i * LDP + j] - del_s[i]) * scale;
+        }
+    __syncthreads();
+
+    // outputs: rows ti+16a, columns tj+16b (< hd)
+    float dq[4][4], dk[4][4], dvv[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) dq[a][b] = dk[a][b] = dvv[a][b] = 0.f;
+    for (int j = 0; j < BW_NK; ++j) {
+        float ds_r[4], ds_c[4], p_c[4], kd[4], qd[4], dd[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            ds_r[a] = Ss[(ti + 16 * a) * LDP + j];   // dS[i][j]   (dQ: sum over keys j)
+            ds_c[a] = Ss[j * LDP + (ti + 16 * a)];   // dS[j][i']  (dK: sum over queries j)
+            p_c[a] = Ps[j * LDP + (ti + 16 * a)];    // P[j][i']   (dV)
+            const int d = tj + 16 * a;
+            const bool dv_ok = d < hd;
+            kd[a] = dv_ok ? Ks[j * LDH + d] : 0.f;
+            qd[a] = dv_ok ? Qs[j * LDH + d] : 0.f;
+            dd[a] = dv_ok ? Ds[j * LDH + d] : 0.f;
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                dq[a][b] += ds_r[a] * kd[b];
+                dk[a][b] += ds_c[a] * qd[b];
+                dvv[a][b] += p_c[a] * dd[b];
+            }
+    }
+    T* __restrict__ dqkv = static_cast<T*>(p.dqkv);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int r = ti + 16 * a;
+        const int qt = qtok_s[r], kt = ktok_s[r];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int d = tj + 16 * b;
+            if (d >= hd) continue;
+            if (qt >= 0) dqkv[(size_t)qt * p.lddqkv + h * hd + d] = from_f<T>(dq[a][b]);
+            if (kt >= 0) {
+                dqkv[(size_t)kt * p.lddqkv + dout + h * hd + d] = from_f<T>(dk[a][b]);
+                dqkv[(size_t)kt * p.lddqkv + 2 * dout + h * hd + d] = from_f<T>(dvv[a][b]);
+            }
+        }
+    }
+}
+
+template <typename T> int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t s) {
+    LSAM_REQUIRE(a.qkv && a.bias && a.dout && a.lse && a.dqkv, LSAM_ERR_BAD_ARG, "attention_bwd: null pointer");
+    LSAM_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.nh > 0, LSAM_ERR_BAD_ARG, "attention_bwd: empty shape");
+    LSAM_REQUIRE(a.ws > 0 && a.ws * a.ws <= BW_NK, LSAM_ERR_UNSUPPORTED,
+                 "attention_bwd: window %d not supported (need 0 < ws*ws <= %d)", a.ws, BW_NK);
+    LSAM_REQUIRE(a.hd > 0 && a.hd <= 64, LSAM_ERR_UNSUPPORTED, "attention_bwd: head_dim %d", a.hd);
+    LSAM_REQUIRE(a.ldqkv >= 3 * a.nh * a.hd && a.lddqkv >= 3 * a.nh * a.hd && a.lddo >= a.nh * a.hd,
+                 LSAM_ERR_BAD_ARG, "attention_bwd: leading dimensions");
+    const int LDH = a.hd + 1, LDP = BW_NK + 1;
+    const size_t lds = (size_t)(4 * BW_NK * LDH + 2 * BW_NK * LDP + 2 * BW_NK) * sizeof(float) + 2 * BW_NK * sizeof(int);
+    auto kern = attn_bwd_kernel<T>;
+    LSAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
+    const int nwy = cdiv(a.H, a.ws), nwx = cdiv(a.W, a.ws);
+    hipLaunchKernelGGL(kern, dim3(a.N * nwy * nwx, a.nh), dim3(256), lds, s, a, 1.0f / sqrtf((float)a.hd));
+    LSAM_LAUNCH_CHECK();
+    return LSAM_OK;
+}
+template int launch_attn_bwd<float>(const AttnBwdArgs&, hipStream_t);
+template int launch_attn_bwd<bf16>(const AttnBwdArgs&, hipStream_t);
+
+}  // namespace lsam

@@ -1,0 +1,107 @@
+// extern "C" entry points for the unit-level operators (see include/lsam.h).
+#include <stdarg.h>
+
+#include "kernels.hpp"
+
+namespace lsam {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace lsam
+
+using namespace lsam;
+
+#define DISPATCH(dtype, CALL_F32, CALL_BF16)                              \
+    do {                                                                  \
+        if ((dtype) == LSAM_F32) return (CALL_F32);                       \
+        if ((dtype) == LSAM_BF16) return (CALL_BF16);                     \
+        set_error("unknown dtype %d", (int)(dtype));                      \
+        return LSAM_ERR_BAD_ARG;                                          \
+    } while (0)
+
+extern "C" {
+
+const char* lsam_last_error(void) { return g_err; }
+int lsam_version(void) { return 1; }
+
+int lsam_linear(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, const float* res,
+                int ldres, int res_row_mod, const void* aux, int ldaux, void* out, int ldo, void* out2, int ldo2,
+                int flags, int M, int N, int K, lsam_stream_t stream) {
+    GemmArgs a{A, lda, W, ldw, bias, res, ldres, res_row_mod, aux, ldaux, out, ldo, out2, ldo2, flags, M, N, K};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DISPATCH(dtype, launch_gemm<float>(a, s), launch_gemm<bf16>(a, s));
+}
+
+int lsam_pack_matrix(int dtype, const float* src, long src_rs, long src_cs, int rows, int cols, void* dst, int ldd,
+                     lsam_stream_t stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DISPATCH(dtype, launch_pack_matrix<float>(src, src_rs, src_cs, rows, cols, static_cast<float*>(dst), ldd, s),
+             launch_pack_matrix<bf16>(src, src_rs, src_cs, rows, cols, static_cast<bf16*>(dst), ldd, s));
+}
+
+int lsam_layernorm_fwd(int dtype, const float* x, int ldx, const float* gamma, const float* beta, void* y, int ldy,
+                       float* stats, int M, int C, float eps, lsam_stream_t stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DISPATCH(dtype, launch_ln_fwd<float>(x, ldx, gamma, beta, static_cast<float*>(y), ldy, stats, M, C, eps, s),
+             launch_ln_fwd<bf16>(x, ldx, gamma, beta, static_cast<bf16*>(y), ldy, stats, M, C, eps, s));
+}
+
+int lsam_layernorm_bwd(int dtype, const float* dy, int lddy, const float* x, int ldx, const float* stats,
+                       const float* gamma, const float* dres, int lddres, float* dx, int lddx, void* dx_t, int lddxt,
+                       int M, int C, lsam_stream_t stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DISPATCH(dtype,
+             launch_ln_bwd<float>(dy, lddy, x, ldx, stats, gamma, dres, lddres, dx, lddx, static_cast<float*>(dx_t),
+                                  lddxt, M, C, s),
+             launch_ln_bwd<bf16>(dy, lddy, x, ldx, stats, gamma, dres, lddres, dx, lddx, static_cast<bf16*>(dx_t),
+                                 lddxt, M, C, s));
+}
+
+int lsam_attention_fwd(int dtype, const void* qkv, int ldqkv, const float* bias, void* out, int ldo, float* lse, int N,
+                       int H, int W, int ws, int pool, int nh, int hd, lsam_stream_t stream) {
+    AttnArgs a{qkv, ldqkv, bias, out, ldo, lse, N, H, W, ws, pool, nh, hd};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DISPATCH(dtype, launch_attn_fwd<float>(a, s), launch_attn_fwd<bf16>(a, s));
+}
+
+int lsam_attention_bwd(int dtype, const void* qkv, int ldqkv, const float* bias, const void* dout, int lddo,
+                       const float* lse, void* dqkv, int lddqkv, int N, int H, int W, int ws, int nh, int hd,
+                       lsam_stream_t stream) {
+    AttnBwdArgs a{qkv, ldqkv, bias, dout, lddo, lse, dqkv, lddqkv, N, H, W, ws, nh, hd};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DISPATCH(dtype, launch_attn_bwd<float>(a, s), launch_attn_bwd<bf16>(a, s));
+}
+
+int lsam_maxpool2x2(const float* x, float* out, int N, int H, int W, int C, lsam_stream_t stream) {
+    return launch_maxpool2x2(x, out, N, H, W, C, static_cast<hipStream_t>(stream));
+}
+
+int lsam_cast(int dtype, const float* src, int lds, void* dst, int ldd, int rows, int cols, lsam_stream_t stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DISPATCH(dtype, launch_cast<float>(src, lds, static_cast<float*>(dst), ldd, rows, cols, s),
+             launch_cast<bf16>(src, lds, static_cast<bf16*>(dst), ldd, rows, cols, s));
+}
+
+int lsam_im2col_patch(int dtype, const float* img, void* cols, int ldc, int N, int S, lsam_stream_t stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DISPATCH(dtype, launch_im2col_patch<float>(img, static_cast<float*>(cols), ldc, N, S, s),
+             launch_im2col_patch<bf16>(img, static_cast<bf16*>(cols), ldc, N, S, s));
+}
+
+size_t lsam_outer_reduce_ws(int M, int C) { return (M > 0 && C > 0) ? outer_reduce_ws(M, C) : 0; }
+
+int lsam_outer_reduce(int dtype, const void* X, int ldx, const void* Y, int ldy, int M, int C, int R, float* out,
+                      long out_cs, long out_ks, void* partial, lsam_stream_t stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DISPATCH(dtype,
+             launch_outer_reduce<float>(static_cast<const float*>(X), ldx, static_cast<const float*>(Y), ldy, M, C, R,
+                                        out, out_cs, out_ks, partial, s),
+             launch_outer_reduce<bf16>(static_cast<const bf16*>(X), ldx, static_cast<const bf16*>(Y), ldy, M, C, R, out,
+                                       out_cs, out_ks, partial, s));
+}
+
+}  // extern "C"

@@ -1,0 +1,132 @@
+// Shared device/host helpers for the LoRA-SAM2 Hiera kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/lsam.h"
+
+namespace lsam {
+
+using bf16 = __bf16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x8 = __attribute__((ext_vector_type(8))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+
+// ---------------------------------------------------------------------------
+// error reporting: never throw, never print; thread-local last-error string
+// ---------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define LSAM_REQUIRE(cond, code, ...)        \
+    do {                                     \
+        if (!(cond)) {                       \
+            ::lsam::set_error(__VA_ARGS__);  \
+            return (code);                   \
+        }                                    \
+    } while (0)
+#define LSAM_HIP(expr)                                                              \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            ::lsam::set_error("%s failed: %s", #expr, hipGetErrorString(e_));       \
+            return LSAM_ERR_HIP;                                                    \
+        }                                                                           \
+    } while (0)
+#define LSAM_TRY(expr)              \
+    do {                            \
+        int rc_ = (expr);           \
+        if (rc_ != LSAM_OK) return rc_; \
+    } while (0)
+// kernel launches report configuration errors through hipGetLastError
+#define LSAM_LAUNCH_CHECK() LSAM_HIP(hipGetLastError())
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------
+// element traits.  A "chunk" is 16 bytes, a "fragment" is the 8 K-elements one
+// lane feeds to a K=32 MFMA macro-step:  lane l holds  X[row = l&15][k = 8*(l>>4) + j].
+// For bf16 that is one v_mfma_f32_16x16x32_bf16; for f32 the same mapping is
+// realised by eight v_mfma_f32_16x16x4_f32 (element j of every lane forms one
+// K=4 step), so both dtypes share all indexing.  C/D layout is dtype-independent:
+// lane l, reg r  ->  D[row = 4*(l>>4) + r][col = l&15].
+// ---------------------------------------------------------------------------
+template <typename T> struct Tr;
+template <> struct Tr<float> {
+    static constexpr int EPC = 4;   // elements per 16-byte chunk
+    static constexpr int CPF = 2;   // chunks per fragment
+    using frag = f32x8;
+    static constexpr int DTYPE = LSAM_F32;
+};
+template <> struct Tr<bf16> {
+    static constexpr int EPC = 8;
+    static constexpr int CPF = 1;
+    using frag = bf16x8;
+    static constexpr int DTYPE = LSAM_BF16;
+};
+
+__device__ __forceinline__ void mma16(const bf16x8& a, const bf16x8& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(const f32x8& a, const f32x8& b, f32x4& c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return (bf16)v; }
+
+// fragment from one or two 16-byte chunks already in registers
+__device__ __forceinline__ bf16x8 make_frag(const uint4& c0, const uint4&, bf16) {
+    return __builtin_bit_cast(bf16x8, c0);
+}
+__device__ __forceinline__ f32x8 make_frag(const uint4& c0, const uint4& c1, float) {
+    f32x4 a = __builtin_bit_cast(f32x4, c0), b = __builtin_bit_cast(f32x4, c1);
+    f32x8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return r;
+}
+
+// 4 consecutive values -> packed store (16 B f32 / 8 B bf16)
+__device__ __forceinline__ void store4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void store4(bf16* p, const f32x4& v) {
+    bf16x4 o;
+    o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+__device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load4(const bf16* p) {
+    bf16x4 o = *reinterpret_cast<const bf16x4*>(p);
+    f32x4 v;
+    v[0] = (float)o[0]; v[1] = (float)o[1]; v[2] = (float)o[2]; v[3] = (float)o[3];
+    return v;
+}
+
+// LDS tile rows are 128 B (8 chunks) or 256 B (16 chunks); chunk index XOR (row&7)
+// makes ds_read_b128 of 16 rows x one chunk column conflict-free (guide T2).
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ (row & 7); }
+
+__device__ __forceinline__ float gelu_f(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// XCD-aware bijective block remap (guide T1): blocks b and b+8 share an XCD, so give
+// every XCD a contiguous run of logical tile ids.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+}  // namespace lsam

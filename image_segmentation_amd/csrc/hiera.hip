@@ -1,0 +1,579 @@
+// Whole-trunk plan: Hiera.forward / get_embedding (hieradet.py:284-334) with LoRA_qkv on the last
+// blocks (lora_qkv.py:102-109,162) as ONE host call that enqueues ~8 kernels per block, and the
+// LoRA-only backward as a second call.  The plan is host-side bookkeeping only: packed weights
+// live in a caller-provided arena, activations in a caller-provided workspace.
+//
+// HBM layout: activations are token-major NHWC ([N*H*W][C]).  The residual stream and the stage
+// outputs are fp32; every GEMM operand is T (bf16 or fp32).  Blocks of a stage update the stage's
+// output buffer in place (x += proj(attn); x += mlp), so a non-differentiated block allocates no
+// residual storage.  The LoRA blocks write their residual states to saved buffers instead, because
+// the backward needs the LN inputs.
+//
+// LoRA is folded into the frozen-qkv MFMA main loop by K-augmentation: the LN1 output buffer
+// carries 32 extra columns u = [xn.A_q^T (16) | xn.A_v^T (16)] and the packed qkv weight carries
+// [B_q rows 0..d | B_v rows 2d..3d] in the matching 32 extra K columns, so
+// qkv = [xn|u].[W|B]^T is the reference's two slice-adds (lora_qkv.py:104-107) with no extra pass
+// over qkv.  The backward re-uses the same trick for dxn = dqkv.W + t_q.A_q + t_v.A_v.
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace lsam {
+
+constexpr int AUG = 32;       // extra K columns: [q part 16 | v part 16]
+constexpr int PATCH_K = 160;  // 3*7*7 = 147 padded to a multiple of 16
+
+struct BlockGeom {
+    int dim, dout, heads, ws, pool, gin, gout, stage;
+    bool lora, need_dx;
+    int kq;  // K of the qkv GEMM (dim or dim + AUG)
+};
+struct BlockOff {
+    size_t ln1w, ln1b, wqkv, bqkv, wproj, bproj, ln2w, ln2b, w1, b1, w2, b2, wsc, bsc;
+    size_t wqkvT, wprojT, w1T, w2T, acat, bT;
+};
+
+}  // namespace lsam
+
+using namespace lsam;
+
+struct lsam_hiera {
+    lsam_hiera_config_t cfg;
+    std::vector<BlockGeom> blk;
+    std::vector<BlockOff> off;
+    int stage_ch[4], stage_grid[4];
+    int grid0;
+    size_t wpatch, bpatch, pos;
+    size_t arena_bytes;
+    size_t esz;
+    int first_lora;
+};
+
+namespace lsam {
+
+struct Bump {
+    size_t cur = 0;
+    size_t take(size_t bytes) {
+        const size_t o = cur;
+        cur = align_up(cur + bytes, 256);
+        return o;
+    }
+};
+
+struct FwdWs {
+    size_t im2col, xn, qkv, scpre, a, hbuf;
+    // per LoRA block (index g = block - first_lora)
+    struct Saved { size_t st1, xn, qkv, lse, y, st2, pre, xout; } sv[8];
+    // backward scratch
+    size_t gT, dh, dyn, dy, dyT, da, dqkv, dxn, dxprev, partial;
+    size_t total;
+};
+
+static FwdWs plan_ws(const lsam_hiera* h, int N, bool with_grad) {
+    FwdWs w{};
+    Bump b;
+    const size_t e = h->esz;
+    const size_t M0 = (size_t)N * h->grid0 * h->grid0;
+    w.im2col = b.take(M0 * PATCH_K * e);
+    size_t xn = 0, qkv = 0, sc = 0, a = 0, hb = 0;
+    for (const BlockGeom& g : h->blk) {
+        const size_t Mi = (size_t)N * g.gin * g.gin, Mo = (size_t)N * g.gout * g.gout;
+        xn = std::max(xn, std::max(Mi * g.kq, Mo * g.dout) * e);
+        qkv = std::max(qkv, Mi * 3 * g.dout * e);
+        if (g.dim != g.dout && g.pool == 2) sc = std::max(sc, Mi * g.dout * sizeof(float));
+        a = std::max(a, Mo * g.dout * e);
+        hb = std::max(hb, Mo * 4 * g.dout * e);
+    }
+    w.xn = b.take(xn);
+    w.qkv = b.take(qkv);
+    w.scpre = b.take(sc);
+    w.a = b.take(a);
+    w.hbuf = b.take(hb);
+    if (with_grad && h->cfg.n_lora_blocks > 0) {
+        const BlockGeom& g = h->blk.back();
+        const size_t M = (size_t)N * g.gin * g.gin, d = g.dim;
+        for (int i = 0; i < h->cfg.n_lora_blocks; ++i) {
+            auto& s = w.sv[i];
+            s.st1 = b.take(M * 2 * sizeof(float));
+            s.xn = b.take(M * (d + AUG) * e);
+            s.qkv = b.take(M * 3 * d * e);
+            s.lse = b.take(M * g.heads * sizeof(float));
+            s.y = b.take(M * d * sizeof(float));
+            s.st2 = b.take(M * 2 * sizeof(float));
+            s.pre = b.take(M * 4 * d * e);
+            s.xout = b.take(M * d * sizeof(float));
+        }
+        w.gT = b.take(M * d * e);
+        w.dh = b.take(M * 4 * d * e);
+        w.dyn = b.take(M * d * sizeof(float));
+        w.dy = b.take(M * d * sizeof(float));
+        w.dyT = b.take(M * d * e);
+        w.da = b.take(M * d * e);
+        w.dqkv = b.take(M * (3 * d + AUG) * e);
+        w.dxn = b.take(M * d * sizeof(float));
+        w.dxprev = b.take(M * d * sizeof(float));
+        w.partial = b.take(outer_reduce_ws((int)M, (int)d));
+    }
+    w.total = b.cur;
+    return w;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LoRA packing: rewrite the LoRA-dependent slices of the packed operands from the fp32 masters.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_lora_kernel(const float* __restrict__ aq, const float* __restrict__ bq,
+                                 const float* __restrict__ av, const float* __restrict__ bv, int d, int r,
+                                 T* __restrict__ wqkv, T* __restrict__ acat, T* __restrict__ bT,
+                                 T* __restrict__ wqkvT) {
+    const int kq = d + AUG, n3 = 3 * d;
+    const long n_w = (long)n3 * AUG, n_a = (long)AUG * d, n_b = (long)AUG * n3, n_t = wqkvT ? (long)d * AUG : 0;
+    const long total = n_w + n_a + n_b + n_t;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        if (i < n_w) {  // wqkv[n][d + j]
+            const int n = (int)(i / AUG), j = (int)(i % AUG);
+            float v = 0.f;
+            if (j < 16) { if (j < r && n < d) v = bq[(size_t)n * r + j]; }
+            else { const int k = j - 16; if (k < r && n >= n3 - d) v = bv[(size_t)(n - (n3 - d)) * r + k]; }
+            wqkv[(size_t)n * kq + d + j] = from_f<T>(v);
+        } else if (i < n_w + n_a) {  // acat[j][c]
+            const long t = i - n_w;
+            const int j = (int)(t / d), c = (int)(t % d);
+            float v = 0.f;
+            if (j < 16) { if (j < r) v = aq[(size_t)j * d + c]; }
+            else if (j - 16 < r) v = av[(size_t)(j - 16) * d + c];
+            acat[t] = from_f<T>(v);
+        } else if (i < n_w + n_a + n_b) {  // bT[j][n]
+            const long t = i - n_w - n_a;
+            const int j = (int)(t / n3), n = (int)(t % n3);
+            float v = 0.f;
+            if (j < 16) { if (j < r && n < d) v = bq[(size_t)n * r + j]; }
+            else { const int k = j - 16; if (k < r && n >= n3 - d) v = bv[(size_t)(n - (n3 - d)) * r + k]; }
+            bT[t] = from_f<T>(v);
+        } else {  // wqkvT[c][3d + j] = A[j][c]
+            const long t = i - n_w - n_a - n_b;
+            const int c = (int)(t / AUG), j = (int)(t % AUG);
+            float v = 0.f;
+            if (j < 16) { if (j < r) v = aq[(size_t)j * d + c]; }
+            else if (j - 16 < r) v = av[(size_t)(j - 16) * d + c];
+            wqkvT[(size_t)c * (n3 + AUG) + n3 + j] = from_f<T>(v);
+        }
+    }
+}
+
+template <typename T> static T* at(void* base, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(base) + off); }
+
+template <typename T>
+static int pack_t(lsam_hiera* h, const lsam_block_params_t* bp, const float* patch_w, const float* patch_b,
+                  const float* pos, void* arena, hipStream_t s) {
+    const int e0 = h->cfg.embed_dim;
+    LSAM_TRY(launch_pack_matrix<T>(patch_w, 147, 1, e0, 147, at<T>(arena, h->wpatch), PATCH_K, s));
+    LSAM_TRY(launch_pack_matrix<float>(patch_b, 0, 1, 1, e0, at<float>(arena, h->bpatch), e0, s));
+    LSAM_TRY(launch_pack_matrix<float>(pos, 0, 1, 1, h->grid0 * h->grid0 * e0, at<float>(arena, h->pos),
+                                       h->grid0 * h->grid0 * e0, s));
+    for (size_t i = 0; i < h->blk.size(); ++i) {
+        const BlockGeom& g = h->blk[i];
+        const BlockOff& o = h->off[i];
+        const lsam_block_params_t& p = bp[i];
+        const int d = g.dim, q = g.dout;
+        LSAM_REQUIRE(p.norm1_w && p.norm1_b && p.qkv_w && p.qkv_b && p.attn_proj_w && p.attn_proj_b && p.norm2_w &&
+                         p.norm2_b && p.fc1_w && p.fc1_b && p.fc2_w && p.fc2_b && (d == q || (p.proj_w && p.proj_b)),
+                     LSAM_ERR_BAD_ARG, "hiera_pack: block %zu has a null parameter", i);
+        auto vec = [&](const float* src, size_t off_, int n) {
+            return launch_pack_matrix<float>(src, 0, 1, 1, n, at<float>(arena, off_), n, s);
+        };
+        LSAM_TRY(vec(p.norm1_w, o.ln1w, d));
+        LSAM_TRY(vec(p.norm1_b, o.ln1b, d));
+        LSAM_TRY(launch_pack_matrix<T>(p.qkv_w, d, 1, 3 * q, d, at<T>(arena, o.wqkv), g.kq, s));
+        LSAM_TRY(vec(p.qkv_b, o.bqkv, 3 * q));
+        LSAM_TRY(launch_pack_matrix<T>(p.attn_proj_w, q, 1, q, q, at<T>(arena, o.wproj), q, s));
+        LSAM_TRY(vec(p.attn_proj_b, o.bproj, q));
+        LSAM_TRY(vec(p.norm2_w, o.ln2w, q));
+        LSAM_TRY(vec(p.norm2_b, o.ln2b, q));
+        LSAM_TRY(launch_pack_matrix<T>(p.fc1_w, q, 1, 4 * q, q, at<T>(arena, o.w1), q, s));
+        LSAM_TRY(vec(p.fc1_b, o.b1, 4 * q));
+        LSAM_TRY(launch_pack_matrix<T>(p.fc2_w, 4 * q, 1, q, 4 * q, at<T>(arena, o.w2), 4 * q, s));
+        LSAM_TRY(vec(p.fc2_b, o.b2, q));
+        if (d != q) {
+            LSAM_TRY(launch_pack_matrix<T>(p.proj_w, d, 1, q, d, at<T>(arena, o.wsc), d, s));
+            LSAM_TRY(vec(p.proj_b, o.bsc, q));
+        }
+        if (g.lora) {  // transposed copies for dX = dY . W   (frozen: no dW GEMMs exist)
+            LSAM_TRY(launch_pack_matrix<T>(p.fc2_w, 1, 4 * q, 4 * q, q, at<T>(arena, o.w2T), q, s));
+            LSAM_TRY(launch_pack_matrix<T>(p.fc1_w, 1, q, q, 4 * q, at<T>(arena, o.w1T), 4 * q, s));
+            LSAM_TRY(launch_pack_matrix<T>(p.attn_proj_w, 1, q, q, q, at<T>(arena, o.wprojT), q, s));
+            if (g.need_dx)
+                LSAM_TRY(launch_pack_matrix<T>(p.qkv_w, 1, d, d, 3 * q, at<T>(arena, o.wqkvT), 3 * q + AUG, s));
+        }
+    }
+    return LSAM_OK;
+}
+
+template <typename T>
+static int pack_lora_t(lsam_hiera* h, const lsam_lora_params_t* lp, void* arena, hipStream_t s) {
+    const int r = h->cfg.lora_rank;
+    for (int i = 0; i < h->cfg.n_lora_blocks; ++i) {
+        const int bi = h->first_lora + i;
+        const BlockGeom& g = h->blk[bi];
+        const BlockOff& o = h->off[bi];
+        LSAM_REQUIRE(lp[i].a_q && lp[i].b_q && lp[i].a_v && lp[i].b_v, LSAM_ERR_BAD_ARG, "pack_lora: null LoRA factor");
+        hipLaunchKernelGGL(pack_lora_kernel<T>, dim3(256), dim3(256), 0, s, lp[i].a_q, lp[i].b_q, lp[i].a_v,
+                           lp[i].b_v, g.dim, r, at<T>(arena, o.wqkv), at<T>(arena, o.acat), at<T>(arena, o.bT),
+                           g.need_dx ? at<T>(arena, o.wqkvT) : (T*)nullptr);
+        LSAM_LAUNCH_CHECK();
+    }
+    return LSAM_OK;
+}
+
+template <typename T>
+static int linear(const T* A, int lda, const T* W, int ldw, const float* bias, const float* res, int ldres,
+                  int res_mod, const T* aux, int ldaux, void* out, int ldo, T* out2, int ldo2, int flags, int M,
+                  int N, int K, hipStream_t s) {
+    GemmArgs a{A, lda, W, ldw, bias, res, ldres, res_mod, aux, ldaux, out, ldo, out2, ldo2, flags, M, N, K};
+    return launch_gemm<T>(a, s);
+}
+
+template <typename T>
+static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage_out, void* arena, void* ws,
+                     const FwdWs& w, bool with_grad, hipStream_t s) {
+    const int e0 = h->cfg.embed_dim, g0 = h->grid0;
+    const int M0 = N * g0 * g0;
+    // PatchEmbed (backbones/utils.py:85-93) + pos embed (hieradet.py:307-312) as im2col + fused GEMM
+    LSAM_TRY(launch_im2col_patch<T>(img, at<T>(ws, w.im2col), PATCH_K, N, h->cfg.img_size, s));
+    LSAM_TRY(linear<T>(at<T>(ws, w.im2col), PATCH_K, at<T>(arena, h->wpatch), PATCH_K, at<float>(arena, h->bpatch),
+                       at<float>(arena, h->pos), e0, g0 * g0, nullptr, 0, stage_out[0], e0, nullptr, 0,
+                       LSAM_EPI_OUT_F32, M0, e0, PATCH_K, s));
+    float* x = stage_out[0];
+    for (size_t i = 0; i < h->blk.size(); ++i) {
+        const BlockGeom& g = h->blk[i];
+        const BlockOff& o = h->off[i];
+        const int d = g.dim, q = g.dout;
+        const int Mi = N * g.gin * g.gin, Mo = N * g.gout * g.gout;
+        const bool grad = with_grad && g.lora;
+        const int gi = (int)i - h->first_lora;
+        const bool last = i + 1 == h->blk.size();
+        // ---- norm1 (+ LoRA u columns) -----------------------------------------------------------
+        T* xn = grad ? at<T>(ws, w.sv[gi].xn) : at<T>(ws, w.xn);
+        LSAM_TRY(launch_ln_fwd<T>(x, d, at<float>(arena, o.ln1w), at<float>(arena, o.ln1b), xn, g.kq,
+                                  (grad && g.need_dx) ? at<float>(ws, w.sv[gi].st1) : nullptr, Mi, d, 1e-6f, s));
+        if (g.lora)
+            LSAM_TRY(linear<T>(xn, g.kq, at<T>(arena, o.acat), d, nullptr, nullptr, 0, 0, nullptr, 0, xn + d, g.kq,
+                               nullptr, 0, 0, Mi, AUG, d, s));
+        // ---- residual target ----------------------------------------------------------------------
+        float* y;
+        if (grad) y = at<float>(ws, w.sv[gi].y);
+        else if (d != q) y = stage_out[g.stage];
+        else y = x;
+        const float* res = x;
+        if (d != q) {  // shortcut = pool(proj(norm1(x)))  (hieradet.py:139-140)
+            float* sc = g.pool == 2 ? at<float>(ws, w.scpre) : y;
+            LSAM_TRY(linear<T>(xn, g.kq, at<T>(arena, o.wsc), d, at<float>(arena, o.bsc), nullptr, 0, 0, nullptr, 0, sc,
+                               q, nullptr, 0, LSAM_EPI_OUT_F32, Mi, q, d, s));
+            if (g.pool == 2) LSAM_TRY(launch_maxpool2x2(sc, y, N, g.gin, g.gin, q, s));
+            res = y;
+        }
+        // ---- qkv (+LoRA through the augmented K columns) ------------------------------------------
+        T* qkv = grad ? at<T>(ws, w.sv[gi].qkv) : at<T>(ws, w.qkv);
+        LSAM_TRY(linear<T>(xn, g.kq, at<T>(arena, o.wqkv), g.kq, at<float>(arena, o.bqkv), nullptr, 0, 0, nullptr, 0,
+                           qkv, 3 * q, nullptr, 0, 0, Mi, 3 * q, g.kq, s));
+        // ---- attention ------------------------------------------------------------------------------
+        T* a = at<T>(ws, w.a);
+        AttnArgs aa{qkv, 3 * q, at<float>(arena, o.bqkv), a, q, grad ? at<float>(ws, w.sv[gi].lse) : nullptr,
+                    N, g.gin, g.gin, g.ws, g.pool, g.heads, q / g.heads};
+        LSAM_TRY(launch_attn_fwd<T>(aa, s));
+        // ---- proj + residual  (hieradet.py:79,163) -------------------------------------------------
+        LSAM_TRY(linear<T>(a, q, at<T>(arena, o.wproj), q, at<float>(arena, o.bproj), res, q, 0, nullptr, 0, y, q,
+                           nullptr, 0, LSAM_EPI_OUT_F32, Mo, q, q, s));
+        // ---- norm2 + MLP + residual  (hieradet.py:165) -----------------------------------------------
+        T* yn = at<T>(ws, w.xn);
+        LSAM_TRY(launch_ln_fwd<T>(y, q, at<float>(arena, o.ln2w), at<float>(arena, o.ln2b), yn, q,
+                                  grad ? at<float>(ws, w.sv[gi].st2) : nullptr, Mo, q, 1e-6f, s));
+        T* hb = at<T>(ws, w.hbuf);
+        LSAM_TRY(linear<T>(yn, q, at<T>(arena, o.w1), q, at<float>(arena, o.b1), nullptr, 0, 0, nullptr, 0, hb, 4 * q,
+                           grad ? at<T>(ws, w.sv[gi].pre) : nullptr, 4 * q,
+                           LSAM_EPI_GELU | (grad ? LSAM_EPI_SAVE_PRE : 0), Mo, 4 * q, q, s));
+        float* out;
+        if (grad) out = last ? stage_out[g.stage] : at<float>(ws, w.sv[gi].xout);
+        else out = y;
+        LSAM_TRY(linear<T>(hb, 4 * q, at<T>(arena, o.w2), 4 * q, at<float>(arena, o.b2), y, q, 0, nullptr, 0, out, q,
+                           nullptr, 0, LSAM_EPI_OUT_F32, Mo, q, 4 * q, s));
+        x = out;
+        // a stage's last block must leave its result in the caller's stage buffer
+        if ((last || h->blk[i + 1].stage != g.stage) && x != stage_out[g.stage]) {
+            LSAM_HIP(hipMemcpyAsync(stage_out[g.stage], x, (size_t)Mo * q * sizeof(float), hipMemcpyDeviceToDevice, s));
+            x = stage_out[g.stage];
+        }
+    }
+    return LSAM_OK;
+}
+
+template <typename T>
+static int backward_t(lsam_hiera* h, const float* grad_out, int N, float* const* lora_grads, void* arena, void* ws,
+                      const FwdWs& w, hipStream_t s) {
+    const int r = h->cfg.lora_rank;
+    const float* dout = grad_out;
+    for (int gi = h->cfg.n_lora_blocks - 1; gi >= 0; --gi) {
+        const int bi = h->first_lora + gi;
+        const BlockGeom& g = h->blk[bi];
+        const BlockOff& o = h->off[bi];
+        const auto& sv = w.sv[gi];
+        const int d = g.dim, M = N * g.gin * g.gin, ldq = 3 * d + AUG;
+        T* gT = at<T>(ws, w.gT);
+        T* dh = at<T>(ws, w.dh);
+        float* dyn = at<float>(ws, w.dyn);
+        float* dy = at<float>(ws, w.dy);
+        T* dyT = at<T>(ws, w.dyT);
+        T* da = at<T>(ws, w.da);
+        T* dqkv = at<T>(ws, w.dqkv);
+        T* xn = at<T>(ws, sv.xn);
+        // out = y + fc2(gelu(fc1(norm2(y))))
+        LSAM_TRY(launch_cast<T>(dout, d, gT, d, M, d, s));
+        LSAM_TRY(linear<T>(gT, d, at<T>(arena, o.w2T), d, nullptr, nullptr, 0, 0, at<T>(ws, sv.pre), 4 * d, dh, 4 * d,
+                           nullptr, 0, LSAM_EPI_GELU_BWD, M, 4 * d, d, s));
+        LSAM_TRY(linear<T>(dh, 4 * d, at<T>(arena, o.w1T), 4 * d, nullptr, nullptr, 0, 0, nullptr, 0, dyn, d, nullptr, 0,
+                           LSAM_EPI_OUT_F32, M, d, 4 * d, s));
+        LSAM_TRY(launch_ln_bwd<T>(dyn, d, at<float>(ws, sv.y), d, at<float>(ws, sv.st2), at<float>(arena, o.ln2w), dout,
+                                  d, dy, d, dyT, d, M, d, s));
+        // y = x + proj(attn(qkv))
+        LSAM_TRY(linear<T>(dyT, d, at<T>(arena, o.wprojT), d, nullptr, nullptr, 0, 0, nullptr, 0, da, d, nullptr, 0, 0, M,
+                           d, d, s));
+        AttnBwdArgs ab{at<T>(ws, sv.qkv), 3 * d, at<float>(arena, o.bqkv), da, d, at<float>(ws, sv.lse), dqkv, ldq,
+                       N, g.gin, g.gin, g.ws, g.heads, d / g.heads};
+        LSAM_TRY(launch_attn_bwd<T>(ab, s));
+        // t = [dq.B_q | dv.B_v] into the 32 augmented columns of dqkv
+        LSAM_TRY(linear<T>(dqkv, ldq, at<T>(arena, o.bT), 3 * d, nullptr, nullptr, 0, 0, nullptr, 0, dqkv + 3 * d, ldq,
+                           nullptr, 0, 0, M, AUG, 3 * d, s));
+        // LoRA gradients (token reductions): dB = dq^T u, dA = t^T xn
+        void* part = at<char>(ws, w.partial);
+        float* const* G = lora_grads + 4 * gi;
+        LSAM_TRY(launch_outer_reduce<T>(xn, g.kq, dqkv + 3 * d, ldq, M, d, r, G[0], 1, d, part, s));            // dA_q
+        LSAM_TRY(launch_outer_reduce<T>(dqkv, ldq, xn + d, g.kq, M, d, r, G[1], r, 1, part, s));                // dB_q
+        LSAM_TRY(launch_outer_reduce<T>(xn, g.kq, dqkv + 3 * d + 16, ldq, M, d, r, G[2], 1, d, part, s));       // dA_v
+        LSAM_TRY(launch_outer_reduce<T>(dqkv + 2 * d, ldq, xn + d + 16, g.kq, M, d, r, G[3], r, 1, part, s));   // dB_v
+        if (g.need_dx) {
+            float* dxn = at<float>(ws, w.dxn);
+            float* dxp = at<float>(ws, w.dxprev);
+            LSAM_TRY(linear<T>(dqkv, ldq, at<T>(arena, o.wqkvT), ldq, nullptr, nullptr, 0, 0, nullptr, 0, dxn, d, nullptr,
+                               0, LSAM_EPI_OUT_F32, M, d, ldq, s));
+            // x_in of this block is the previous LoRA block's saved output
+            const float* xin = at<float>(ws, w.sv[gi - 1].xout);
+            LSAM_TRY(launch_ln_bwd<T>(dxn, d, xin, d, at<float>(ws, sv.st1), at<float>(arena, o.ln1w), dy, d, dxp, d,
+                                      (T*)nullptr, 0, M, d, s));
+            dout = dxp;
+        }
+    }
+    return LSAM_OK;
+}
+
+}  // namespace lsam
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int lsam_hiera_create(const lsam_hiera_config_t* c, lsam_hiera_t** out) {
+    LSAM_REQUIRE(c && out, LSAM_ERR_BAD_ARG, "hiera_create: null argument");
+    LSAM_REQUIRE(c->dtype == LSAM_F32 || c->dtype == LSAM_BF16, LSAM_ERR_BAD_ARG, "hiera_create: dtype");
+    LSAM_REQUIRE(c->num_stages >= 1 && c->num_stages <= 4, LSAM_ERR_UNSUPPORTED, "hiera_create: 1..4 stages");
+    LSAM_REQUIRE(c->img_size > 0 && c->img_size % 4 == 0, LSAM_ERR_UNSUPPORTED, "hiera_create: img_size %% 4");
+    LSAM_REQUIRE(c->embed_dim > 0 && c->embed_dim % 8 == 0 && c->num_heads > 0, LSAM_ERR_UNSUPPORTED,
+                 "hiera_create: embed_dim must be a multiple of 8");
+    LSAM_REQUIRE(c->n_global >= 0 && c->n_global <= 8, LSAM_ERR_BAD_ARG, "hiera_create: n_global");
+    LSAM_REQUIRE(c->lora_rank >= 0 && c->lora_rank <= 16, LSAM_ERR_UNSUPPORTED, "hiera_create: lora_rank <= 16");
+    LSAM_REQUIRE(c->n_lora_blocks >= 0 && c->n_lora_blocks <= 8 && (c->lora_rank > 0 || c->n_lora_blocks == 0),
+                 LSAM_ERR_BAD_ARG, "hiera_create: n_lora_blocks");
+    lsam_hiera* h = new (std::nothrow) lsam_hiera();
+    LSAM_REQUIRE(h, LSAM_ERR_BAD_ARG, "hiera_create: out of host memory");
+    h->cfg = *c;
+    h->esz = c->dtype == LSAM_BF16 ? 2 : 4;
+    h->grid0 = c->img_size / 4;
+    // geometry, as Hiera.__init__ derives it (hieradet.py:203-260)
+    int depth = 0, stage_end[4];
+    for (int s = 0; s < c->num_stages; ++s) {
+        depth += c->stages[s];
+        stage_end[s] = depth - 1;
+    }
+    int dim = c->embed_dim, heads = c->num_heads, cur_stage = 1, grid = h->grid0;
+    for (int i = 0; i < depth; ++i) {
+        BlockGeom g{};
+        g.dim = dim;
+        g.dout = dim;
+        int ws = c->window_spec[cur_stage - 1];  // lags by one block (hieradet.py:237-240)
+        for (int k = 0; k < c->n_global; ++k)
+            if (c->global_att_blocks[k] == i) ws = 0;
+        bool first_of_stage = false, pooled = false;
+        for (int s = 0; s + 1 < c->num_stages; ++s)
+            if (i - 1 == stage_end[s]) {
+                first_of_stage = true;
+                pooled = s < c->q_pool;
+            }
+        if (first_of_stage) {
+            g.dout = dim * 2;
+            heads *= 2;
+            cur_stage += 1;
+        }
+        g.heads = heads;
+        g.ws = ws;
+        g.pool = pooled ? 2 : 1;
+        g.gin = grid;
+        g.gout = pooled ? grid / 2 : grid;
+        g.stage = cur_stage - 1;
+        g.lora = c->n_lora_blocks > 0 && i >= depth - c->n_lora_blocks;
+        g.need_dx = g.lora && i > depth - c->n_lora_blocks;
+        g.kq = g.lora ? g.dim + AUG : g.dim;
+        h->blk.push_back(g);
+        dim = g.dout;
+        grid = g.gout;
+    }
+    h->first_lora = depth - c->n_lora_blocks;
+    int rc = LSAM_OK;
+    for (int i = 0; i < depth && rc == LSAM_OK; ++i) {
+        const BlockGeom& g = h->blk[i];
+        if (g.dout % g.heads != 0 || (g.dout / g.heads) % 8 != 0 || g.dout / g.heads > 64) {
+            set_error("hiera_create: block %d head_dim %d unsupported (need %%8==0, <=64)", i, g.dout / g.heads);
+            rc = LSAM_ERR_UNSUPPORTED;
+        } else if (g.pool == 2 && (g.ws <= 0 || g.ws % 2 || g.gin % 2)) {
+            set_error("hiera_create: q-pool block %d needs an even window and grid", i);
+            rc = LSAM_ERR_UNSUPPORTED;
+        } else if (g.lora && (g.dim != g.dout || g.pool != 1 || g.ws <= 0 || g.ws * g.ws > 64)) {
+            set_error("hiera_create: LoRA block %d must be a same-width windowed block with <= 64 keys", i);
+            rc = LSAM_ERR_UNSUPPORTED;
+        }
+    }
+    if (rc != LSAM_OK) {
+        delete h;
+        return rc;
+    }
+    for (int s = 0; s < c->num_stages; ++s) {
+        h->stage_ch[s] = h->blk[stage_end[s]].dout;
+        h->stage_grid[s] = h->blk[stage_end[s]].gout;
+    }
+    // arena layout
+    Bump b;
+    const size_t e = h->esz;
+    h->wpatch = b.take((size_t)c->embed_dim * PATCH_K * e);
+    h->bpatch = b.take((size_t)c->embed_dim * 4);
+    h->pos = b.take((size_t)h->grid0 * h->grid0 * c->embed_dim * 4);
+    for (int i = 0; i < depth; ++i) {
+        const BlockGeom& g = h->blk[i];
+        const size_t d = g.dim, q = g.dout;
+        BlockOff o{};
+        o.ln1w = b.take(d * 4);
+        o.ln1b = b.take(d * 4);
+        o.wqkv = b.take(3 * q * g.kq * e);
+        o.bqkv = b.take(3 * q * 4);
+        o.wproj = b.take(q * q * e);
+        o.bproj = b.take(q * 4);
+        o.ln2w = b.take(q * 4);
+        o.ln2b = b.take(q * 4);
+        o.w1 = b.take(4 * q * q * e);
+        o.b1 = b.take(4 * q * 4);
+        o.w2 = b.take(4 * q * q * e);
+        o.b2 = b.take(q * 4);
+        if (d != q) {
+            o.wsc = b.take(q * d * e);
+            o.bsc = b.take(q * 4);
+        }
+        if (g.lora) {
+            o.w2T = b.take(4 * q * q * e);
+            o.w1T = b.take(4 * q * q * e);
+            o.wprojT = b.take(q * q * e);
+            o.wqkvT = b.take(d * (3 * q + AUG) * e);
+            o.acat = b.take((size_t)AUG * d * e);
+            o.bT = b.take((size_t)AUG * 3 * q * e);
+        }
+        h->off.push_back(o);
+    }
+    h->arena_bytes = b.cur;
+    *out = h;
+    return LSAM_OK;
+}
+
+void lsam_hiera_destroy(lsam_hiera_t* h) { delete h; }
+
+int lsam_hiera_num_blocks(const lsam_hiera_t* h) { return h ? (int)h->blk.size() : 0; }
+
+int lsam_hiera_block_info(const lsam_hiera_t* h, int i, int* dim, int* dim_out, int* heads, int* window, int* pool,
+                          int* grid) {
+    LSAM_REQUIRE(h && i >= 0 && i < (int)h->blk.size(), LSAM_ERR_BAD_ARG, "block_info: bad index");
+    const BlockGeom& g = h->blk[i];
+    if (dim) *dim = g.dim;
+    if (dim_out) *dim_out = g.dout;
+    if (heads) *heads = g.heads;
+    if (window) *window = g.ws;
+    if (pool) *pool = g.pool == 2;
+    if (grid) *grid = g.gin;
+    return LSAM_OK;
+}
+
+int lsam_hiera_stage_info(const lsam_hiera_t* h, int s, int* channels, int* grid) {
+    LSAM_REQUIRE(h && s >= 0 && s < h->cfg.num_stages, LSAM_ERR_BAD_ARG, "stage_info: bad index");
+    if (channels) *channels = h->stage_ch[s];
+    if (grid) *grid = h->stage_grid[s];
+    return LSAM_OK;
+}
+
+size_t lsam_hiera_arena_bytes(const lsam_hiera_t* h) { return h ? h->arena_bytes : 0; }
+
+size_t lsam_hiera_workspace_bytes(const lsam_hiera_t* h, int batch, int with_grad) {
+    if (!h || batch <= 0) return 0;
+    return plan_ws(h, batch, with_grad != 0).total;
+}
+
+int lsam_hiera_pack(lsam_hiera_t* h, const lsam_block_params_t* host_blocks, const float* patch_w,
+                    const float* patch_b, const float* pos, void* arena, size_t arena_bytes, lsam_stream_t stream) {
+    LSAM_REQUIRE(h && host_blocks && patch_w && patch_b && pos && arena, LSAM_ERR_BAD_ARG, "hiera_pack: null argument");
+    LSAM_REQUIRE(arena_bytes >= h->arena_bytes, LSAM_ERR_WORKSPACE, "hiera_pack: arena %zu < %zu bytes", arena_bytes,
+                 h->arena_bytes);
+    LSAM_REQUIRE((reinterpret_cast<uintptr_t>(arena) & 255) == 0, LSAM_ERR_BAD_ARG, "hiera_pack: arena must be 256-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (h->cfg.dtype == LSAM_BF16) return pack_t<bf16>(h, host_blocks, patch_w, patch_b, pos, arena, s);
+    return pack_t<float>(h, host_blocks, patch_w, patch_b, pos, arena, s);
+}
+
+int lsam_hiera_pack_lora(lsam_hiera_t* h, const lsam_lora_params_t* host_lora, void* arena, lsam_stream_t stream) {
+    LSAM_REQUIRE(h && arena, LSAM_ERR_BAD_ARG, "pack_lora: null argument");
+    if (h->cfg.n_lora_blocks == 0) return LSAM_OK;
+    LSAM_REQUIRE(host_lora, LSAM_ERR_BAD_ARG, "pack_lora: null LoRA parameter table");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (h->cfg.dtype == LSAM_BF16) return pack_lora_t<bf16>(h, host_lora, arena, s);
+    return pack_lora_t<float>(h, host_lora, arena, s);
+}
+
+int lsam_hiera_forward(lsam_hiera_t* h, const float* img, int batch, float* const* host_stage_out, void* arena,
+                       void* workspace, size_t workspace_bytes, int with_grad, lsam_stream_t stream) {
+    LSAM_REQUIRE(h && img && host_stage_out && arena && workspace, LSAM_ERR_BAD_ARG, "hiera_forward: null argument");
+    LSAM_REQUIRE(batch > 0, LSAM_ERR_BAD_ARG, "hiera_forward: batch must be positive");
+    for (int s = 0; s < h->cfg.num_stages; ++s)
+        LSAM_REQUIRE(host_stage_out[s] && aligned16(host_stage_out[s]), LSAM_ERR_BAD_ARG,
+                     "hiera_forward: stage output %d null or misaligned", s);
+    LSAM_REQUIRE(aligned16(img) && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0, LSAM_ERR_BAD_ARG,
+                 "hiera_forward: img must be 16-byte and workspace 256-byte aligned");
+    const bool wg = with_grad != 0 && h->cfg.n_lora_blocks > 0;
+    const FwdWs w = plan_ws(h, batch, wg);
+    LSAM_REQUIRE(workspace_bytes >= w.total, LSAM_ERR_WORKSPACE, "hiera_forward: workspace %zu < %zu bytes",
+                 workspace_bytes, w.total);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (h->cfg.dtype == LSAM_BF16) return forward_t<bf16>(h, img, batch, host_stage_out, arena, workspace, w, wg, s);
+    return forward_t<float>(h, img, batch, host_stage_out, arena, workspace, w, wg, s);
+}
+
+int lsam_hiera_backward(lsam_hiera_t* h, const float* grad_out, int batch, float* const* host_lora_grads, void* arena,
+                        void* workspace, size_t workspace_bytes, lsam_stream_t stream) {
+    LSAM_REQUIRE(h && grad_out && host_lora_grads && arena && workspace, LSAM_ERR_BAD_ARG, "hiera_backward: null argument");
+    LSAM_REQUIRE(h->cfg.n_lora_blocks > 0, LSAM_ERR_BAD_ARG, "hiera_backward: plan has no LoRA blocks");
+    LSAM_REQUIRE(batch > 0 && aligned16(grad_out), LSAM_ERR_BAD_ARG, "hiera_backward: batch / grad alignment");
+    for (int i = 0; i < 4 * h->cfg.n_lora_blocks; ++i)
+        LSAM_REQUIRE(host_lora_grads[i], LSAM_ERR_BAD_ARG, "hiera_backward: null gradient buffer %d", i);
+    const FwdWs w = plan_ws(h, batch, true);
+    LSAM_REQUIRE(workspace_bytes >= w.total, LSAM_ERR_WORKSPACE, "hiera_backward: workspace %zu < %zu bytes",
+                 workspace_bytes, w.total);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (h->cfg.dtype == LSAM_BF16) return backward_t<bf16>(h, grad_out, batch, host_lora_grads, arena, workspace, w, s);
+    return backward_t<float>(h, grad_out, batch, host_lora_grads, arena, workspace, w, s);
+}
+
+}  // extern "C"

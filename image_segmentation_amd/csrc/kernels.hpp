@@ -1,0 +1,61 @@
+// Internal typed launchers shared by the C ABI (capi.hip) and the trunk plan (hiera.hip).
+#pragma once
+#include "common.hpp"
+
+namespace lsam {
+
+struct GemmArgs {
+    const void* A; int lda;
+    const void* W; int ldw;
+    const float* bias;
+    const float* res; int ldres; int res_row_mod;
+    const void* aux; int ldaux;
+    void* out; int ldo;
+    void* out2; int ldo2;
+    int flags;
+    int M, N, K;
+};
+template <typename T> int launch_gemm(const GemmArgs& a, hipStream_t s);
+
+template <typename T>
+int launch_pack_matrix(const float* src, long src_rs, long src_cs, int rows, int cols, T* dst, int ldd,
+                       hipStream_t s);
+template <typename T>
+int launch_ln_fwd(const float* x, int ldx, const float* gamma, const float* beta, T* y, int ldy,
+                  float* stats, int M, int C, float eps, hipStream_t s);
+template <typename T>
+int launch_ln_bwd(const float* dy, int lddy, const float* x, int ldx, const float* stats,
+                  const float* gamma, const float* dres, int lddres, float* dx, int lddx, T* dx_t,
+                  int lddxt, int M, int C, hipStream_t s);
+
+struct AttnArgs {
+    const void* qkv; int ldqkv;
+    const float* bias;
+    void* out; int ldo;
+    float* lse;
+    int N, H, W, ws, pool, nh, hd;
+};
+template <typename T> int launch_attn_fwd(const AttnArgs& a, hipStream_t s);
+
+struct AttnBwdArgs {
+    const void* qkv; int ldqkv;
+    const float* bias;
+    const void* dout; int lddo;
+    const float* lse;
+    void* dqkv; int lddqkv;
+    int N, H, W, ws, nh, hd;
+};
+template <typename T> int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t s);
+
+int launch_maxpool2x2(const float* x, float* out, int N, int H, int W, int C, hipStream_t s);
+template <typename T>
+int launch_cast(const float* src, int lds, T* dst, int ldd, int rows, int cols, hipStream_t s);
+template <typename T>
+int launch_im2col_patch(const float* img, T* cols, int ldc, int N, int S, hipStream_t s);
+
+size_t outer_reduce_ws(int M, int C);
+template <typename T>
+int launch_outer_reduce(const T* X, int ldx, const T* Y, int ldy, int M, int C, int R, float* out,
+                        long out_cs, long out_ks, void* partial, hipStream_t s);
+
+}  // namespace lsam

@@ -1,0 +1,162 @@
+"""Tensor-level wrappers over the C ABI (one call = one HIP kernel launch or two).
+
+These exist for the parity tests and for the stand-alone drop-in modules
+(`LoRA_qkv`, `MultiScaleBlock` used outside a `Hiera`).  The trunk hot path does not
+go through here: `Hiera.forward` makes a single `lsam_hiera_forward` call.
+Everything requires CUDA(HIP) tensors; nothing here computes in PyTorch."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _C
+from ._C import check, dtype_code, lib, ptr, stream
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _C.LsamError("liblsam operators need tensors on the MI355X (cuda) device; "
+                               "there is no CPU fallback")
+
+
+def _rows2d(t: torch.Tensor) -> Tuple[int, int, int]:
+    """(rows, cols, ld) of a 2-D tensor whose rows are contiguous."""
+    assert t.dim() == 2 and t.stride(1) == 1, "expect row-major 2-D tensor"
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+def pack_matrix(src: torch.Tensor, dtype: torch.dtype, ld: Optional[int] = None) -> torch.Tensor:
+    """fp32 2-D (any strides, e.g. a transposed view) -> packed T [rows, ld], zero padded."""
+    _need_gpu(src)
+    assert src.dim() == 2 and src.dtype == torch.float32
+    rows, cols = src.shape
+    ld = cols if ld is None else ld
+    dst = torch.empty(rows, ld, dtype=dtype, device=src.device)
+    check(lib().lsam_pack_matrix(dtype_code(dtype), ptr(src), src.stride(0), src.stride(1), rows, cols,
+                                 ptr(dst), ld, stream()))
+    return dst
+
+
+def linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
+           res: Optional[torch.Tensor] = None, res_row_mod: int = 0, gelu: bool = False,
+           gelu_bwd_aux: Optional[torch.Tensor] = None, out_f32: bool = False, save_pre: bool = False,
+           out: Optional[torch.Tensor] = None, K: Optional[int] = None, N: Optional[int] = None):
+    """out = epilogue(A[:, :K] @ W[:N, :K].T + bias) + res   (see lsam_linear)."""
+    _need_gpu(A, W, bias, res)
+    assert A.dtype == W.dtype
+    M, Ka, lda = _rows2d(A)
+    Nw, Kw, ldw = _rows2d(W)
+    K = min(Ka, Kw) if K is None else K
+    N = Nw if N is None else N
+    odt = torch.float32 if out_f32 else A.dtype
+    if out is None:
+        out = torch.empty(M, N, dtype=odt, device=A.device)
+    assert out.dtype == odt
+    _, _, ldo = _rows2d(out)
+    out2 = torch.empty(M, N, dtype=A.dtype, device=A.device) if save_pre else None
+    flags = (_C.EPI_GELU if gelu else 0) | (_C.EPI_GELU_BWD if gelu_bwd_aux is not None else 0) | \
+        (_C.EPI_OUT_F32 if out_f32 else 0) | (_C.EPI_SAVE_PRE if save_pre else 0)
+    ldres = res.stride(0) if res is not None else 0
+    ldaux = gelu_bwd_aux.stride(0) if gelu_bwd_aux is not None else 0
+    check(lib().lsam_linear(dtype_code(A.dtype), ptr(A), lda, ptr(W), ldw, ptr(bias), ptr(res), ldres,
+                            res_row_mod, ptr(gelu_bwd_aux), ldaux, ptr(out), ldo, ptr(out2),
+                            N if save_pre else 0, flags, M, N, K, stream()))
+    return (out, out2) if save_pre else out
+
+
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, dtype: torch.dtype,
+                  ld: Optional[int] = None, want_stats: bool = False, eps: float = 1e-6):
+    _need_gpu(x, gamma, beta)
+    M, Cc, ldx = _rows2d(x)
+    ld = Cc if ld is None else ld
+    y = torch.zeros(M, ld, dtype=dtype, device=x.device) if ld != Cc else \
+        torch.empty(M, ld, dtype=dtype, device=x.device)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=x.device) if want_stats else None
+    check(lib().lsam_layernorm_fwd(dtype_code(dtype), ptr(x), ldx, ptr(gamma), ptr(beta), ptr(y), ld,
+                                   ptr(stats), M, Cc, eps, stream()))
+    return (y, stats) if want_stats else y
+
+
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor,
+                  dres: Optional[torch.Tensor], dtype: torch.dtype):
+    _need_gpu(dy, x, stats, gamma, dres)
+    M, Cc, lddy = _rows2d(dy)
+    dx = torch.empty(M, Cc, dtype=torch.float32, device=x.device)
+    dxt = torch.empty(M, Cc, dtype=dtype, device=x.device)
+    check(lib().lsam_layernorm_bwd(dtype_code(dtype), ptr(dy), lddy, ptr(x), x.stride(0), ptr(stats),
+                                   ptr(gamma), ptr(dres), dres.stride(0) if dres is not None else 0,
+                                   ptr(dx), Cc, ptr(dxt), Cc, M, Cc, stream()))
+    return dx, dxt
+
+
+def attention_fwd(qkv: torch.Tensor, bias: torch.Tensor, ws: int, pool: int, nh: int,
+                  want_lse: bool = False):
+    """qkv T [N,H,W,3*nh*hd] (contiguous) -> out T [N,H/pool,W/pool,nh*hd] (+ lse fp32 [N,H',W',nh])."""
+    _need_gpu(qkv, bias)
+    assert qkv.dim() == 4 and qkv.is_contiguous()
+    N, H, W, C3 = qkv.shape
+    dout = C3 // 3
+    hd = dout // nh
+    Ho, Wo = H // pool, W // pool
+    out = torch.empty(N, Ho, Wo, dout, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(N, Ho, Wo, nh, dtype=torch.float32, device=qkv.device) if want_lse else None
+    check(lib().lsam_attention_fwd(dtype_code(qkv.dtype), ptr(qkv), C3, ptr(bias), ptr(out), dout,
+                                   ptr(lse), N, H, W, ws, pool, nh, hd, stream()))
+    return (out, lse) if want_lse else out
+
+
+def attention_bwd(qkv: torch.Tensor, bias: torch.Tensor, dout_t: torch.Tensor, lse: torch.Tensor,
+                  ws: int, nh: int, ld_out: Optional[int] = None) -> torch.Tensor:
+    _need_gpu(qkv, bias, dout_t, lse)
+    N, H, W, C3 = qkv.shape
+    d = C3 // 3
+    ld = C3 if ld_out is None else ld_out
+    dqkv = torch.zeros(N, H, W, ld, dtype=qkv.dtype, device=qkv.device)
+    check(lib().lsam_attention_bwd(dtype_code(qkv.dtype), ptr(qkv), C3, ptr(bias), ptr(dout_t), d,
+                                   ptr(lse), ptr(dqkv), ld, N, H, W, ws, nh, d // nh, stream()))
+    return dqkv
+
+
+def maxpool2x2(x: torch.Tensor) -> torch.Tensor:
+    _need_gpu(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    N, H, W, Cc = x.shape
+    out = torch.empty(N, H // 2, W // 2, Cc, dtype=torch.float32, device=x.device)
+    check(lib().lsam_maxpool2x2(ptr(x), ptr(out), N, H, W, Cc, stream()))
+    return out
+
+
+def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    _need_gpu(x)
+    rows, cols, lds = _rows2d(x)
+    out = torch.empty(rows, cols, dtype=dtype, device=x.device)
+    check(lib().lsam_cast(dtype_code(dtype), ptr(x), lds, ptr(out), cols, rows, cols, stream()))
+    return out
+
+
+def im2col_patch(img: torch.Tensor, dtype: torch.dtype, ldc: int = 160) -> torch.Tensor:
+    _need_gpu(img)
+    assert img.dtype == torch.float32 and img.is_contiguous()
+    N, _, S, _ = img.shape
+    cols = torch.empty(N * (S // 4) ** 2, ldc, dtype=dtype, device=img.device)
+    check(lib().lsam_im2col_patch(dtype_code(dtype), ptr(img), ptr(cols), ldc, N, S, stream()))
+    return cols
+
+
+def outer_reduce(X: torch.Tensor, Y: torch.Tensor, R: int, transpose_out: bool) -> torch.Tensor:
+    """G[c][k] = sum_m X[m][c] Y[m][k]; returns [C,R] or, with transpose_out, [R,C]."""
+    _need_gpu(X, Y)
+    M, Cc, ldx = _rows2d(X)
+    _, _, ldy = _rows2d(Y)
+    ws = torch.empty(lib().lsam_outer_reduce_ws(M, Cc), dtype=torch.uint8, device=X.device)
+    if transpose_out:
+        out = torch.empty(R, Cc, dtype=torch.float32, device=X.device)
+        cs, ks = 1, Cc
+    else:
+        out = torch.empty(Cc, R, dtype=torch.float32, device=X.device)
+        cs, ks = R, 1
+    check(lib().lsam_outer_reduce(dtype_code(X.dtype), ptr(X), ldx, ptr(Y), ldy, M, Cc, R, ptr(out), cs, ks,
+                                  ptr(ws), stream()))
+    return out

@@ -1,0 +1,200 @@
+/* lsam.h -- C ABI of liblsam.so: MI355X (gfx950) kernels for the LoRA-SAM2 Hiera
+ * image-encoder hot path.
+ *
+ * The reference (DonWick32/image-segmentation) has NO FFI on this path: it is pure
+ * PyTorch behind nn.Module interfaces.  These entry points are what
+ * this repo's drop-in modules (the .py files of image_segmentation_amd) bind through ctypes in
+ * place of the torch ops the reference modules call; each cites the reference lines
+ * it replaces.  INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions: plain pointers and sizes only; all pointers are DEVICE pointers unless
+ * named host_*; every function returns LSAM_OK (0) or a negative error code and
+ * never throws, allocates device memory, or synchronises the stream.  The message
+ * for the calling thread's last error is lsam_last_error().  Work is enqueued on the
+ * given hipStream_t (pass torch.cuda.current_stream().cuda_stream).  Functions are
+ * re-entrant across threads (autograd-engine thread vs. main thread) as long as
+ * two calls do not share a workspace.
+ *
+ * dtype: LSAM_F32 computes in exact-fp32 MFMA (v_mfma_f32_16x16x4_f32); LSAM_BF16
+ * computes in bf16 MFMA with fp32 accumulation.  "T" below means float or bf16
+ * storage accordingly.  The residual stream, LayerNorm statistics, biases, LSE and all
+ * LoRA gradients are fp32 in both modes.
+ */
+#ifndef LSAM_H
+#define LSAM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* lsam_stream_t; /* hipStream_t */
+
+enum { LSAM_F32 = 0, LSAM_BF16 = 1 };
+enum {
+    LSAM_OK = 0,
+    LSAM_ERR_BAD_ARG = -1,     /* null / misaligned pointer, bad size */
+    LSAM_ERR_UNSUPPORTED = -2, /* shape the kernels do not cover */
+    LSAM_ERR_HIP = -3,         /* a HIP runtime call failed */
+    LSAM_ERR_WORKSPACE = -4    /* caller workspace too small */
+};
+
+const char* lsam_last_error(void);
+int lsam_version(void);
+
+/* ---- epilogue flags for lsam_linear ---- */
+enum {
+    LSAM_EPI_GELU = 1,      /* out = gelu(acc + bias)           (sam2_utils.py:133, nn.GELU exact erf) */
+    LSAM_EPI_GELU_BWD = 2,  /* out = acc * gelu'(aux)           (autograd of the same)                  */
+    LSAM_EPI_OUT_F32 = 4,   /* out is float* even in bf16 mode                                         */
+    LSAM_EPI_SAVE_PRE = 8   /* also write (acc + bias) before the activation to out2 (T)                */
+};
+
+/* out[M,N] = epilogue( A[M,K] . W[N,K]^T + bias[N] ) + res
+ * Replaces nn.Linear -> addmm (hieradet.py:59,79,132; sam2_utils.py:133) with the bias,
+ * GELU and residual add (hieradet.py:163,165) fused into the MFMA epilogue.
+ * A, W are T with leading dimensions lda, ldw (elements; rows 16-byte aligned, K % 16 == 0);
+ * bias (nullable) fp32; res (nullable) fp32 [M or res_row_mod rows][ldres], row index
+ * m % res_row_mod when res_row_mod > 0 (used for the positional embedding, hieradet.py:312);
+ * aux (GELU_BWD) is T [M][ldaux]; out is T (or fp32 with LSAM_EPI_OUT_F32) [M][ldo];
+ * out2 (SAVE_PRE) is T [M][ldo2].  N % 8 == 0.  In-place res == out is allowed. */
+int lsam_linear(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias,
+                const float* res, int ldres, int res_row_mod, const void* aux, int ldaux,
+                void* out, int ldo, void* out2, int ldo2, int flags, int M, int N, int K,
+                lsam_stream_t stream);
+
+/* dst[r][c] = (T) src[r*src_rs + c*src_cs] for r<rows, c<cols; zero for cols <= c < ldd.
+ * Used to pack frozen fp32 weights (and their transposes for the backward) once. */
+int lsam_pack_matrix(int dtype, const float* src, long src_rs, long src_cs, int rows, int cols,
+                     void* dst, int ldd, lsam_stream_t stream);
+
+/* y[m, 0:C] = (T) LayerNorm(x[m, 0:C]) * gamma + beta   (nn.LayerNorm(eps=1e-6), hieradet.py:100,136,165)
+ * x fp32 [M][ldx]; y T [M][ldy]; stats (nullable) fp32 [M][2] = (mean, rstd). C % 4 == 0. */
+int lsam_layernorm_fwd(int dtype, const float* x, int ldx, const float* gamma, const float* beta,
+                       void* y, int ldy, float* stats, int M, int C, float eps, lsam_stream_t stream);
+
+/* dx[m,:] = dres[m,:] + LN'(dy[m,:]) ; optional T copy of dx.  Only the input gradient: the
+ * affine parameters are frozen (lora_qkv.py:159-160).  dy, dres(nullable), x, dx fp32. */
+int lsam_layernorm_bwd(int dtype, const float* dy, int lddy, const float* x, int ldx,
+                       const float* stats, const float* gamma, const float* dres, int lddres,
+                       float* dx, int lddx, void* dx_t, int lddxt, int M, int C,
+                       lsam_stream_t stream);
+
+/* Windowed / global multi-head attention with Hiera q-pooling, reading the qkv GEMM output in
+ * natural token order and writing the un-partitioned, cropped result.  Replaces
+ * window_partition + reshape/unbind + do_pool(q) + F.scaled_dot_product_attention + transpose
+ * + window_unpartition (backbones/utils.py:16-60, hieradet.py:59-77,142-161).
+ *   qkv  T [N,H,W, 3*nh*hd]  channel order [q|k|v][head][hd]  (hieradet.py:59-61)
+ *   bias fp32 [3*nh*hd]: value of qkv on the zero-pad tokens, which take part as keys
+ *        (padding happens after LN1, hieradet.py:136,146)
+ *   ws   window size, 0 = global;  pool 1 or 2 (2x2 max over q inside each window)
+ *   out  T [N, H/pool, W/pool, nh*hd];  lse (nullable) fp32 [N*(H/pool)*(W/pool)][nh]
+ * hd % 8 == 0, hd <= 64. */
+int lsam_attention_fwd(int dtype, const void* qkv, int ldqkv, const float* bias, void* out, int ldo,
+                       float* lse, int N, int H, int W, int ws, int pool, int nh, int hd,
+                       lsam_stream_t stream);
+
+/* Backward of the above for un-pooled windows with ws*ws <= 64 (the LoRA blocks):
+ *   dout T [N,H,W,nh*hd] -> dqkv T [N,H,W, lddqkv] (q|k|v gradients of the real tokens; the
+ *   zero-pad tokens' k/v are constants and get no gradient). */
+int lsam_attention_bwd(int dtype, const void* qkv, int ldqkv, const float* bias, const void* dout,
+                       int lddo, const float* lse, void* dqkv, int lddqkv, int N, int H, int W,
+                       int ws, int nh, int hd, lsam_stream_t stream);
+
+/* out[n,h/2,w/2,:] = max over the 2x2 block (do_pool on the shortcut, hieradet.py:140). fp32 NHWC. */
+int lsam_maxpool2x2(const float* x, float* out, int N, int H, int W, int C, lsam_stream_t stream);
+
+/* fp32 -> T copy of a [rows][cols] matrix (ld in elements). */
+int lsam_cast(int dtype, const float* src, int lds, void* dst, int ldd, int rows, int cols,
+              lsam_stream_t stream);
+
+/* im2col for PatchEmbed's 7x7 stride-4 pad-3 conv (backbones/utils.py:85-93):
+ * img fp32 [N,3,S,S] -> cols T [N*(S/4)^2][ldc], k = c*49 + ky*7 + kx, zero beyond 147. */
+int lsam_im2col_patch(int dtype, const float* img, void* cols, int ldc, int N, int S,
+                      lsam_stream_t stream);
+
+/* G[c][k] = sum_m X[m][c] * Y[m][k]  (k < R <= 16): the LoRA dA / dB token reductions
+ * (autograd of lora_qkv.py:104-105), deterministic two-pass split over m.
+ * X T [M][ldx] (C columns), Y T [M][ldy]; out fp32 at out[c*out_cs + k*out_ks];
+ * partial: fp32 workspace of lsam_outer_reduce_ws(M, C) bytes. */
+size_t lsam_outer_reduce_ws(int M, int C);
+int lsam_outer_reduce(int dtype, const void* X, int ldx, const void* Y, int ldy, int M, int C, int R,
+                      float* out, long out_cs, long out_ks, void* partial, lsam_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Whole-trunk plan: Hiera.forward / Hiera.get_embedding (hieradet.py:284-334) with
+ * LoRA_qkv on the last blocks (lora_qkv.py:102-109,162) and the autograd graph that
+ * core_loss.backward() walks (train_lora_sam.py:172), as two calls.
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    int dtype;            /* LSAM_F32 / LSAM_BF16 */
+    int img_size;         /* square input, multiple of 32 */
+    int embed_dim;        /* Hiera(embed_dim=...) hieradet.py:176 */
+    int num_heads;        /* initial heads :177 */
+    int num_stages;       /* len(stages) <= 4 */
+    int stages[4];        /* blocks per stage :181 */
+    int window_spec[4];   /* :186 */
+    int n_global;         /* len(global_att_blocks) */
+    int global_att_blocks[8];
+    int q_pool;           /* number of q-pool stages :179 */
+    int lora_rank;        /* 0 = no LoRA; <= 16 */
+    int n_lora_blocks;    /* trunk.blocks[-n:] wrapped & differentiated (2 in the reference, lora_qkv.py:162) */
+} lsam_hiera_config_t;
+
+typedef struct lsam_hiera lsam_hiera_t; /* host-side plan; owns no device memory */
+
+/* fp32 master parameters of one MultiScaleBlock (device pointers, nn.Parameter layout). */
+typedef struct {
+    const float *norm1_w, *norm1_b;   /* [dim] */
+    const float *qkv_w, *qkv_b;       /* [3*dim_out, dim], [3*dim_out] */
+    const float *attn_proj_w, *attn_proj_b; /* [dim_out, dim_out] */
+    const float *norm2_w, *norm2_b;   /* [dim_out] */
+    const float *fc1_w, *fc1_b;       /* [4*dim_out, dim_out] */
+    const float *fc2_w, *fc2_b;       /* [dim_out, 4*dim_out] */
+    const float *proj_w, *proj_b;     /* [dim_out, dim] or NULL (hieradet.py:131-132) */
+} lsam_block_params_t;
+
+typedef struct {
+    const float *a_q, *b_q, *a_v, *b_v; /* [r,d], [d,r], [r,d], [d,r]  (lora_qkv.py:168-171) */
+} lsam_lora_params_t;
+
+int lsam_hiera_create(const lsam_hiera_config_t* cfg, lsam_hiera_t** out);
+void lsam_hiera_destroy(lsam_hiera_t* h);
+int lsam_hiera_num_blocks(const lsam_hiera_t* h);
+/* geometry of block i: dim, dim_out, heads, window, q-pool (0/1), input grid side */
+int lsam_hiera_block_info(const lsam_hiera_t* h, int i, int* dim, int* dim_out, int* heads,
+                          int* window, int* pool, int* grid);
+/* stage s output: channels and grid side */
+int lsam_hiera_stage_info(const lsam_hiera_t* h, int s, int* channels, int* grid);
+
+size_t lsam_hiera_arena_bytes(const lsam_hiera_t* h);                 /* packed weights */
+size_t lsam_hiera_workspace_bytes(const lsam_hiera_t* h, int batch, int with_grad);
+
+/* Pack the frozen parameters into the arena (once, or after load_state_dict).
+ * host_blocks: array of num_blocks structs (host memory) holding device pointers.
+ * pos: fp32 [grid0*grid0][embed_dim], the interpolated+tiled positional embedding
+ * (hieradet.py:273-281), constant per shape. */
+int lsam_hiera_pack(lsam_hiera_t* h, const lsam_block_params_t* host_blocks, const float* patch_w,
+                    const float* patch_b, const float* pos, void* arena, size_t arena_bytes,
+                    lsam_stream_t stream);
+/* Refresh the LoRA-dependent packed operands (every optimiser step). host_lora: n_lora_blocks. */
+int lsam_hiera_pack_lora(lsam_hiera_t* h, const lsam_lora_params_t* host_lora, void* arena,
+                         lsam_stream_t stream);
+
+/* img fp32 [batch,3,S,S] -> host_stage_out[s] fp32 NHWC [batch, g_s, g_s, C_s] (device pointers
+ * in a host array).  with_grad != 0 keeps what lsam_hiera_backward needs in the workspace. */
+int lsam_hiera_forward(lsam_hiera_t* h, const float* img, int batch, float* const* host_stage_out,
+                       void* arena, void* workspace, size_t workspace_bytes, int with_grad,
+                       lsam_stream_t stream);
+/* grad_out fp32 NHWC gradient of the LAST stage output -> host_lora_grads[4*i + {0:a_q,1:b_q,2:a_v,3:b_v}]
+ * fp32, same shapes as the parameters, OVERWRITTEN (not accumulated).  Only LoRA factors get
+ * gradients; no weight-gradient GEMM is run for any frozen tensor. */
+int lsam_hiera_backward(lsam_hiera_t* h, const float* grad_out, int batch,
+                        float* const* host_lora_grads, void* arena, void* workspace,
+                        size_t workspace_bytes, lsam_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSAM_H */
