@@ -92,6 +92,12 @@ int lsam_im2col_patch(int dtype, const float* img, void* cols, int ldc, int N, i
              launch_im2col_patch<bf16>(img, static_cast<bf16*>(cols), ldc, N, S, s));
 }
 
+int lsam_prof_arm(int capacity) { return prof_arm(capacity); }
+int lsam_prof_read(int max, float* host_ms, double* host_flops, int* host_cfg) {
+    LSAM_REQUIRE(host_ms && host_flops && host_cfg && max >= 0, LSAM_ERR_BAD_ARG, "prof_read: null argument");
+    return prof_read(max, host_ms, host_flops, host_cfg);
+}
+
 size_t lsam_outer_reduce_ws(int M, int C) { return (M > 0 && C > 0) ? outer_reduce_ws(M, C) : 0; }
 
 int lsam_outer_reduce(int dtype, const void* X, int ldx, const void* Y, int ldy, int M, int C, int R, float* out,

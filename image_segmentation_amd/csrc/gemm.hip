@@ -10,6 +10,8 @@
 //
 // Hiera-B+ layer widths are all multiples of 112 = 7*16, hence the 128 x 112 tile; other widths
 // use 128 x 128 with column guards.
+#include <stdlib.h>
+
 #include "kernels.hpp"
 
 namespace lsam {
@@ -151,6 +153,43 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Optional per-launch timing of the GEMM kernels (bench.py's live roofline measurement).  OFF by
+// default; when armed, every launch is bracketed by a pre-created hipEvent pair on the launch
+// stream.  Process-global and not thread-safe by design: a measurement aid, not part of the path.
+// ---------------------------------------------------------------------------------------------
+struct ProfRec { hipEvent_t e0, e1; double flops; int cfg; };
+static ProfRec* g_prof = nullptr;
+static int g_prof_cap = 0, g_prof_n = 0;
+static bool g_prof_on = false;
+
+int prof_arm(int capacity) {
+    if (capacity > g_prof_cap) {
+        ProfRec* n = static_cast<ProfRec*>(realloc(g_prof, sizeof(ProfRec) * capacity));
+        LSAM_REQUIRE(n, LSAM_ERR_BAD_ARG, "prof: out of host memory");
+        g_prof = n;
+        for (int i = g_prof_cap; i < capacity; ++i) {
+            LSAM_HIP(hipEventCreate(&g_prof[i].e0));
+            LSAM_HIP(hipEventCreate(&g_prof[i].e1));
+        }
+        g_prof_cap = capacity;
+    }
+    g_prof_n = 0;
+    g_prof_on = capacity > 0;
+    return LSAM_OK;
+}
+int prof_read(int max, float* ms, double* flops, int* cfg) {
+    g_prof_on = false;
+    const int n = g_prof_n < max ? g_prof_n : max;
+    for (int i = 0; i < n; ++i) {
+        LSAM_HIP(hipEventSynchronize(g_prof[i].e1));
+        LSAM_HIP(hipEventElapsedTime(&ms[i], g_prof[i].e0, g_prof[i].e1));
+        flops[i] = g_prof[i].flops;
+        cfg[i] = g_prof[i].cfg;
+    }
+    return n;
+}
+
 template <typename T, int MT, int NT, int WM, int WN>
 static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
@@ -163,8 +202,16 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
         attr_set = true;
     }
     const int nblk = cdiv(a.M, BM) * cdiv(a.N, BN);
+    const bool prof = g_prof_on && g_prof_n < g_prof_cap;
+    if (prof) LSAM_HIP(hipEventRecord(g_prof[g_prof_n].e0, s));
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * WM * WN), LDS, s, a);
     LSAM_LAUNCH_CHECK();
+    if (prof) {
+        LSAM_HIP(hipEventRecord(g_prof[g_prof_n].e1, s));
+        g_prof[g_prof_n].flops = 2.0 * a.M * a.N * a.K;
+        g_prof[g_prof_n].cfg = (int)sizeof(T) * 1000 + BN;
+        ++g_prof_n;
+    }
     return LSAM_OK;
 }
 

@@ -16,6 +16,8 @@ struct GemmArgs {
     int M, N, K;
 };
 template <typename T> int launch_gemm(const GemmArgs& a, hipStream_t s);
+int prof_arm(int capacity);
+int prof_read(int max, float* ms, double* flops, int* cfg);
 
 template <typename T>
 int launch_pack_matrix(const float* src, long src_rs, long src_cs, int rows, int cols, T* dst, int ldd,

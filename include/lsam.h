@@ -43,6 +43,14 @@ enum {
 const char* lsam_last_error(void);
 int lsam_version(void);
 
+/* Measurement aid (no counterpart in the reference; used by bench.py for the live roofline figure):
+ * lsam_prof_arm(n) brackets each of the next n lsam_linear-kernel launches (from any entry point)
+ * with a hipEvent pair on the launch stream; lsam_prof_read disarms, waits for the events and
+ * returns per-launch milliseconds, 2*M*N*K, and a kernel id (1000*sizeof(T) + tile width) into
+ * HOST arrays; returns the count.  Process-global, not thread-safe, off by default. */
+int lsam_prof_arm(int capacity);
+int lsam_prof_read(int max, float* host_ms, double* host_flops, int* host_cfg);
+
 /* ---- epilogue flags for lsam_linear ---- */
 enum {
     LSAM_EPI_GELU = 1,      /* out = gelu(acc + bias)           (sam2_utils.py:133, nn.GELU exact erf) */
