@@ -155,7 +155,7 @@ def main():
         ms = (C.c_float * cap)()
         fl = (C.c_double * cap)()
         cfg = (C.c_int * cap)()
-        n = _C.lib().lsam_prof_read(cap, ms, fl, cfg)
+        n = _C.lib().lsam_prof_read(cap, ms, fl, cfg, None)
         sel = [i for i in range(n) if cfg[i] == 2112]
         tot_ms = sum(ms[i] for i in sel)
         tot_fl = sum(fl[i] for i in sel)

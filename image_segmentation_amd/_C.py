@@ -81,7 +81,7 @@ def lib() -> C.CDLL:
         L.lsam_im2col_patch.argtypes = [i, vp, vp, i, i, i, vp]
         L.lsam_outer_reduce.argtypes = [i, vp, i, vp, i, i, i, i, vp, l, l, vp, vp]
         L.lsam_prof_arm.argtypes = [i]
-        L.lsam_prof_read.argtypes = [i, vp, vp, vp]
+        L.lsam_prof_read.argtypes = [i, vp, vp, vp, vp]
         _lib = L
     return _lib
 

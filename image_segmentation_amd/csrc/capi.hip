@@ -93,9 +93,9 @@ int lsam_im2col_patch(int dtype, const float* img, void* cols, int ldc, int N, i
 }
 
 int lsam_prof_arm(int capacity) { return prof_arm(capacity); }
-int lsam_prof_read(int max, float* host_ms, double* host_flops, int* host_cfg) {
+int lsam_prof_read(int max, float* host_ms, double* host_flops, int* host_cfg, int* host_mnk) {
     LSAM_REQUIRE(host_ms && host_flops && host_cfg && max >= 0, LSAM_ERR_BAD_ARG, "prof_read: null argument");
-    return prof_read(max, host_ms, host_flops, host_cfg);
+    return prof_read(max, host_ms, host_flops, host_cfg, host_mnk);
 }
 
 size_t lsam_outer_reduce_ws(int M, int C) { return (M > 0 && C > 0) ? outer_reduce_ws(M, C) : 0; }

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
 // default; when armed, every launch is bracketed by a pre-created hipEvent pair on the launch
 // stream.  Process-global and not thread-safe by design: a measurement aid, not part of the path.
 // ---------------------------------------------------------------------------------------------
-struct ProfRec { hipEvent_t e0, e1; double flops; int cfg; };
+struct ProfRec { hipEvent_t e0, e1; double flops; int cfg, m, n, k; };
 static ProfRec* g_prof = nullptr;
 static int g_prof_cap = 0, g_prof_n = 0;
 static bool g_prof_on = false;
@@ -178,7 +178,7 @@ int prof_arm(int capacity) {
     g_prof_on = capacity > 0;
     return LSAM_OK;
 }
-int prof_read(int max, float* ms, double* flops, int* cfg) {
+int prof_read(int max, float* ms, double* flops, int* cfg, int* mnk) {
     g_prof_on = false;
     const int n = g_prof_n < max ? g_prof_n : max;
     for (int i = 0; i < n; ++i) {
@@ -186,6 +186,7 @@ int prof_read(int max, float* ms, double* flops, int* cfg) {
         LSAM_HIP(hipEventElapsedTime(&ms[i], g_prof[i].e0, g_prof[i].e1));
         flops[i] = g_prof[i].flops;
         cfg[i] = g_prof[i].cfg;
+        if (mnk) { mnk[3 * i] = g_prof[i].m; mnk[3 * i + 1] = g_prof[i].n; mnk[3 * i + 2] = g_prof[i].k; }
     }
     return n;
 }
@@ -210,6 +211,7 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
         LSAM_HIP(hipEventRecord(g_prof[g_prof_n].e1, s));
         g_prof[g_prof_n].flops = 2.0 * a.M * a.N * a.K;
         g_prof[g_prof_n].cfg = (int)sizeof(T) * 1000 + BN;
+        g_prof[g_prof_n].m = a.M; g_prof[g_prof_n].n = a.N; g_prof[g_prof_n].k = a.K;
         ++g_prof_n;
     }
     return LSAM_OK;

@@ -17,7 +17,7 @@ struct GemmArgs {
 };
 template <typename T> int launch_gemm(const GemmArgs& a, hipStream_t s);
 int prof_arm(int capacity);
-int prof_read(int max, float* ms, double* flops, int* cfg);
+int prof_read(int max, float* ms, double* flops, int* cfg, int* mnk);
 
 template <typename T>
 int launch_pack_matrix(const float* src, long src_rs, long src_cs, int rows, int cols, T* dst, int ldd,

@@ -49,7 +49,7 @@ int lsam_version(void);
  * returns per-launch milliseconds, 2*M*N*K, and a kernel id (1000*sizeof(T) + tile width) into
  * HOST arrays; returns the count.  Process-global, not thread-safe, off by default. */
 int lsam_prof_arm(int capacity);
-int lsam_prof_read(int max, float* host_ms, double* host_flops, int* host_cfg);
+int lsam_prof_read(int max, float* host_ms, double* host_flops, int* host_cfg, int* host_mnk /* nullable [3*max] */);
 
 /* ---- epilogue flags for lsam_linear ---- */
 enum {
