@@ -113,13 +113,28 @@ __device__ __forceinline__ f32x4 load4(const bf16* p) {
 // makes ds_read_b128 of 16 rows x one chunk column conflict-free (guide T2).
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ (row & 7); }
 
-__device__ __forceinline__ float gelu_f(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+// Exact-erf GELU (nn.GELU() default).  The fp32 path uses libm erff; the bf16 path, whose result is
+// rounded to 8 significant bits anyway, uses the Abramowitz-Stegun 7.1.26 rational form
+// (|abs err| < 1.5e-7, ~15 VALU ops instead of erff's ~50): the epilogue of the fc1 GEMM evaluates it
+// on 4 x dim_out values per token, which is enough to make a compute-bound GEMM VALU-bound.
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float y = fmaf(1.061405429f, t, -1.453152027f);
+    y = fmaf(y, t, 1.421413741f);
+    y = fmaf(y, t, -0.284496736f);
+    y = fmaf(y, t, 0.254829592f);
+    y = y * t * __expf(-ax * ax);
+    return copysignf(1.0f - y, x);
 }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+template <bool FAST> __device__ __forceinline__ float gelu_t(float x) {
+    const float e = FAST ? erf_fast(x * 0.70710678118654752f) : erff(x * 0.70710678118654752f);
+    return 0.5f * x * (1.0f + e);
+}
+template <bool FAST> __device__ __forceinline__ float gelu_grad_t(float x) {
+    const float e = FAST ? erf_fast(x * 0.70710678118654752f) : erff(x * 0.70710678118654752f);
     const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    return 0.5f * (1.0f + e) + x * pdf;
 }
 
 // XCD-aware bijective block remap (guide T1): blocks b and b+8 share an XCD, so give

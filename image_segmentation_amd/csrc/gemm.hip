@@ -137,18 +137,191 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
             if (flags & LSAM_EPI_SAVE_PRE) store4(static_cast<T*>(p.out2) + (size_t)m * p.ldo2 + n, v);
             if (flags & LSAM_EPI_GELU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+                for (int r = 0; r < 4; ++r) v[r] = gelu_t<sizeof(T) == 2>(v[r]);
             }
             if (flags & LSAM_EPI_GELU_BWD) {
                 const f32x4 x = load4(static_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_f(x[r]);
+                for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_t<sizeof(T) == 2>(x[r]);
             }
             if (p.res) v += load4(p.res + rm * p.ldres + n);
             if (out_f32)
                 store4(static_cast<float*>(p.out) + (size_t)m * p.ldo + n, v);
             else
                 store4(static_cast<T*>(p.out) + (size_t)m * p.ldo + n, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// v2: 256 x 112 tile, 4 waves of 64 x 112 (28 accumulator tiles each), operands staged by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR round trip, no ds_write), single LDS stage of 46 KiB so three
+// workgroups share a CU and hide each other's load latency.  One wave-instruction of the DMA writes
+// 1 KiB = 8 rows x 128 B linearly, so the XOR swizzle is applied to the per-lane SOURCE address
+// (guide rule 21); out-of-range rows / k-chunks read a 16-byte zero word instead.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+__device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
+template <typename T>
+__global__ __launch_bounds__(256, 3) void gemm2_kernel(const GemmArgs p) {
+    constexpr int EPC = Tr<T>::EPC, CPF = Tr<T>::CPF;
+    constexpr int MT = 4, NT = 7, BM = 256, BN = 112, ROWS = BM + BN;
+    constexpr int BK = 8 * EPC, KS = 8 / (4 * CPF);
+    constexpr int NINSTR = ROWS / 8;              // 46 DMA wave-instructions per k-tile
+    constexpr int PER_WAVE = (NINSTR + 3) / 4;    // 12
+    using frag = typename Tr<T>::frag;
+
+    __shared__ __attribute__((aligned(1024))) char smem[ROWS * 128];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, lr = lane & 15;
+    const int M = p.M, N = p.N, K = p.K;
+    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+    const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int m0 = (id / tiles_n) * BM, n0 = (id % tiles_n) * BN;
+    const T* __restrict__ A = static_cast<const T*>(p.A);
+    const T* __restrict__ Wt = static_cast<const T*>(p.W);
+
+    // per-lane DMA sources: instruction j = wave + 4 i covers tile rows 8j .. 8j+7; i < 8 are the A
+    // rows (j < 32), i >= 8 the W rows, so consecutive i are 32 rows apart in the same matrix.
+    // Buffer addressing: 32-bit byte offsets, and the hardware range check turns every
+    // out-of-range row / k-chunk (offset forced to 0xFFFFFFFF) into zeros.
+    const int lrow = lane >> 3, ck = ((lane & 7) ^ lrow) * EPC;   // source k offset of this lane's chunk
+    const int arow0 = m0 + 8 * wave + lrow, wrow0 = n0 + 8 * wave + lrow;
+    const unsigned aoff0 = ((unsigned)arow0 * (unsigned)p.lda + ck) * (unsigned)sizeof(T);
+    const unsigned woff0 = ((unsigned)wrow0 * (unsigned)p.ldw + ck) * (unsigned)sizeof(T);
+    const unsigned astep = 32u * (unsigned)p.lda * (unsigned)sizeof(T), wstep = 32u * (unsigned)p.ldw * (unsigned)sizeof(T);
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(A), 0,
+                                                         (int)(((size_t)(M - 1) * p.lda + K) * sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Wt), 0,
+                                                         (int)(((size_t)(N - 1) * p.ldw + K) * sizeof(T)), 0x00020000);
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto read_frag = [&](int row, int c0) -> frag {
+        const uint4 x0 = *reinterpret_cast<const uint4*>(smem + row * 128 + (swz(row, c0) << 4));
+        uint4 x1 = x0;
+        if constexpr (CPF == 2) x1 = *reinterpret_cast<const uint4*>(smem + row * 128 + (swz(row, c0 + 1) << 4));
+        return make_frag(x0, x1, T{});
+    };
+
+    const int nkt = (K + BK - 1) / BK;
+#pragma nounroll
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt > 0) __syncthreads();   // every wave has finished reading the previous tile
+        const int k0 = kt * BK;
+        const bool kok = k0 + ck < K;
+        const unsigned kb = (unsigned)k0 * (unsigned)sizeof(T);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned vo = (arow0 + 32 * i < M && kok) ? aoff0 + i * astep + kb : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_ptr_t)(smem + (wave + 4 * i) * 1024), 16, vo, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < PER_WAVE - 8; ++i) {
+            const int j = 32 + wave + 4 * i;
+            if (j < NINSTR) {
+                const unsigned vo = (wrow0 + 32 * i < N && kok) ? woff0 + i * wstep + kb : 0xFFFFFFFFu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(smem + j * 1024), 16, vo, 0, 0, 0);
+            }
+        }
+        __syncthreads();               // DMA landed (vmcnt(0)) and visible to all waves
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int c0 = (ks * 4 + g) * CPF;
+            frag af[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = read_frag(wave * 64 + mt * 16 + lr, c0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const frag wf = read_frag(BM + nt * 16 + lr, c0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) mma16(wf, af[mt], acc[mt][nt]);
+            }
+        }
+    }
+
+    // ---- epilogue.  Lane (lr, g) holds C[m][16 nt + 4 g .. +3].  fp32 results go out as 16-byte
+    // stores (64 contiguous bytes per row and instruction).  For bf16 results the natural 8-byte
+    // store leaves 32-byte row fragments, which the memory system handles at ~1 TB/s; instead two
+    // neighbouring column tiles are regrouped across the four lanes of a row with
+    // v_permlane32_swap + v_permlane16_swap so every lane stores 16 bytes = 8 consecutive columns.
+    const int flags = p.flags;
+    const bool out_f32 = (flags & LSAM_EPI_OUT_F32) || sizeof(T) == 4;
+    auto finish = [&](f32x4 v, int m, size_t rm, int n, f32x4& pre) {
+        if (p.bias) v += load4(p.bias + n);
+        pre = v;
+        if (flags & LSAM_EPI_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_t<sizeof(T) == 2>(v[r]);
+        }
+        if (flags & LSAM_EPI_GELU_BWD) {
+            const f32x4 x = load4(static_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_t<sizeof(T) == 2>(x[r]);
+        }
+        if (p.res) v += load4(p.res + rm * p.ldres + n);
+        return v;
+    };
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + wave * 64 + mt * 16 + lr;
+        const bool mok = m < M;
+        const int mc = mok ? m : M - 1;   // clamp: every lane stays active for the cross-lane swaps
+        const size_t rm = p.res_row_mod > 0 ? (size_t)(mc % p.res_row_mod) : (size_t)mc;
+        if (out_f32) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = n0 + nt * 16 + 4 * g;
+                f32x4 pre;
+                const f32x4 v = finish(acc[mt][nt], mc, rm, n, pre);
+                if (!mok) continue;
+                if (flags & LSAM_EPI_SAVE_PRE) store4(static_cast<T*>(p.out2) + (size_t)m * p.ldo2 + n, pre);
+                store4(static_cast<float*>(p.out) + (size_t)m * p.ldo + n, v);
+            }
+        } else {
+            if constexpr (sizeof(T) == 2) {
+                auto pack2 = [](const f32x4& v) -> uint2 {
+                    bf16x4 o;
+                    o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
+                    return __builtin_bit_cast(uint2, o);
+                };
+                auto store_pair = [&](bf16* base, int ld, uint2 x, uint2 y, int ncol0) {
+                    auto r0 = __builtin_amdgcn_permlane32_swap(x.x, y.x, false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(x.y, y.y, false, false);
+                    auto q0 = __builtin_amdgcn_permlane16_swap(r0[0], r0[1], false, false);
+                    auto q1 = __builtin_amdgcn_permlane16_swap(r1[0], r1[1], false, false);
+                    if (mok)
+                        *reinterpret_cast<uint4*>(base + (size_t)m * ld + ncol0 + 8 * g) =
+                            make_uint4(q0[0], q1[0], q0[1], q1[1]);
+                };
+#pragma unroll
+                for (int nt = 0; nt + 1 < NT; nt += 2) {
+                    f32x4 pa, pb;
+                    const f32x4 va = finish(acc[mt][nt], mc, rm, n0 + nt * 16 + 4 * g, pa);
+                    const f32x4 vb = finish(acc[mt][nt + 1], mc, rm, n0 + (nt + 1) * 16 + 4 * g, pb);
+                    if (flags & LSAM_EPI_SAVE_PRE)
+                        store_pair(static_cast<bf16*>(p.out2), p.ldo2, pack2(pa), pack2(pb), n0 + nt * 16);
+                    store_pair(static_cast<bf16*>(p.out), p.ldo, pack2(va), pack2(vb), n0 + nt * 16);
+                }
+                {
+                    constexpr int nt = NT - 1;
+                    const int n = n0 + nt * 16 + 4 * g;
+                    f32x4 pre;
+                    const f32x4 v = finish(acc[mt][nt], mc, rm, n, pre);
+                    if (mok) {
+                        if (flags & LSAM_EPI_SAVE_PRE) store4(static_cast<T*>(p.out2) + (size_t)m * p.ldo2 + n, pre);
+                        store4(static_cast<T*>(p.out) + (size_t)m * p.ldo + n, v);
+                    }
+                }
+            }
         }
     }
 }
@@ -217,6 +390,22 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     return LSAM_OK;
 }
 
+template <typename T> static int launch_v2(const GemmArgs& a, hipStream_t s) {
+    const int nblk = cdiv(a.M, 256) * cdiv(a.N, 112);
+    const bool prof = g_prof_on && g_prof_n < g_prof_cap;
+    if (prof) LSAM_HIP(hipEventRecord(g_prof[g_prof_n].e0, s));
+    hipLaunchKernelGGL(gemm2_kernel<T>, dim3(nblk), dim3(256), 0, s, a);
+    LSAM_LAUNCH_CHECK();
+    if (prof) {
+        LSAM_HIP(hipEventRecord(g_prof[g_prof_n].e1, s));
+        g_prof[g_prof_n].flops = 2.0 * a.M * a.N * a.K;
+        g_prof[g_prof_n].cfg = (int)sizeof(T) * 1000 + 112;
+        g_prof[g_prof_n].m = a.M; g_prof[g_prof_n].n = a.N; g_prof[g_prof_n].k = a.K;
+        ++g_prof_n;
+    }
+    return LSAM_OK;
+}
+
 template <typename T> int launch_gemm(const GemmArgs& a, hipStream_t s) {
     constexpr int EPC = Tr<T>::EPC;
     LSAM_REQUIRE(a.A && a.W && a.out, LSAM_ERR_BAD_ARG, "linear: null operand");
@@ -233,6 +422,9 @@ template <typename T> int launch_gemm(const GemmArgs& a, hipStream_t s) {
                  "linear: GELU_BWD needs aux");
     LSAM_REQUIRE(!(a.flags & LSAM_EPI_SAVE_PRE) || (a.out2 && a.ldo2 % 4 == 0), LSAM_ERR_BAD_ARG,
                  "linear: SAVE_PRE needs out2");
+    if (a.N % 112 == 0 && (double)a.M * a.lda * sizeof(T) < 2.0e9 && (double)a.N * a.ldw * sizeof(T) < 2.0e9 && a.M >= 1024 &&
+        a.ldo % 8 == 0 && (!(a.flags & LSAM_EPI_SAVE_PRE) || (a.ldo2 % 8 == 0 && aligned16(a.out2))))
+        return launch_v2<T>(a, s);
     if (a.N % 112 == 0) return launch_cfg<T, 2, 7, 4, 1>(a, s);
     return launch_cfg<T, 4, 4, 2, 2>(a, s);
 }

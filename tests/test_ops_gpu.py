@@ -31,7 +31,10 @@ def ops():
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(256, 336, 112), (200, 112, 448), (128, 256, 896), (77, 32, 224),
-                                   (512, 2688, 928), (130, 56, 160)])
+                                   (512, 2688, 928), (130, 56, 160),
+                                   # >= 1024 rows and N % 112 == 0: the LDS-DMA 256x112-tile kernel, incl. ragged M / K tails
+                                   (1101, 336, 112), (2048, 448, 448), (1500, 112, 1792), (1024, 2688, 928),
+                                   (4099, 224, 224), (1280, 112, 160)])
 def test_linear_bias_res(ops, dt, M, N, K):
     A, W, b, res = rnd(M, K, seed=1), rnd(N, K, seed=2) / math.sqrt(K), rnd(N, seed=3), rnd(M, N, seed=4)
     Ad, Wd = A.cuda().to(dt), W.cuda().to(dt)
@@ -44,8 +47,9 @@ def test_linear_bias_res(ops, dt, M, N, K):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-def test_linear_epilogues(ops, dt):
-    M, N, K = 192, 448, 112
+@pytest.mark.parametrize("M", [192, 1216])
+def test_linear_epilogues(ops, dt, M):
+    N, K = 448, 112
     A, W, b = rnd(M, K, seed=1).cuda().to(dt), (rnd(N, K, seed=2) / math.sqrt(K)).cuda().to(dt), rnd(N, seed=3).cuda()
     pre_ref = A.float().cpu().double() @ W.float().cpu().double().t() + b.cpu().double()
     out, pre = ops.linear(A, W, b, gelu=True, save_pre=True)
@@ -54,7 +58,7 @@ def test_linear_epilogues(ops, dt):
     # row-periodic residual (positional embedding)
     pos = rnd(64, N, seed=5).cuda()
     out = ops.linear(A, W, b, res=pos, res_row_mod=64, out_f32=True)
-    assert rel_err(out, pre_ref + pos.cpu().double().repeat(3, 1)) < 1e-6
+    assert rel_err(out, pre_ref + pos.cpu().double().repeat(M // 64, 1)) < 1e-6
     # GELU backward epilogue: out = acc * gelu'(aux)
     aux = rnd(M, N, seed=6).cuda().to(dt)
     out = ops.linear(A, W, None, gelu_bwd_aux=aux, out_f32=True)
