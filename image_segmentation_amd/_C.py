@@ -74,7 +74,7 @@ def lib() -> C.CDLL:
         L.lsam_pack_matrix.argtypes = [i, vp, l, l, i, i, vp, i, vp]
         L.lsam_layernorm_fwd.argtypes = [i, vp, i, vp, vp, vp, i, vp, i, i, f, vp]
         L.lsam_layernorm_bwd.argtypes = [i, vp, i, vp, i, vp, vp, vp, i, vp, i, vp, i, i, i, vp]
-        L.lsam_attention_fwd.argtypes = [i, vp, i, vp, vp, i, vp, i, i, i, i, i, i, i, vp]
+        L.lsam_attention_fwd.argtypes = [i, vp, i, vp, vp, vp, i, vp, i, i, i, i, i, i, i, vp]
         L.lsam_attention_bwd.argtypes = [i, vp, i, vp, vp, i, vp, vp, i, i, i, i, i, i, i, vp]
         L.lsam_maxpool2x2.argtypes = [vp, vp, i, i, i, i, vp]
         L.lsam_cast.argtypes = [i, vp, i, vp, i, i, i, vp]

@@ -262,6 +262,240 @@ __global__ void attn_fwd_kernel(const AttnArgs p, const float c_log2) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v2 (bf16, windows with >= 128 keys and global attention).  Same arithmetic as above, different
+// data movement:
+//  * K and V tiles of 64 keys go global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round
+//    trip), double-buffered: the DMA of tile t+1 is issued right after the barrier that publishes
+//    tile t and lands while tile t is being multiplied (one barrier per tile).
+//  * both tiles are row-major [key][64 d] with the chunk-XOR swizzle applied on the per-lane
+//    SOURCE address; V^T fragments come straight out of the row-major V tile with the transposing
+//    LDS read ds_read_b64_tr_b16, so no transposed copy of V is ever written.
+//  * pad tokens (k, v = bias) are fetched from a bf16 copy of the bias, masked keys / the d >= hd
+//    tail from a 16-byte zero word, through the same per-lane source pointer.
+// One workgroup = 4 waves x QT query tiles of 16 = one (window, head, block of 64*QT queries).
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_vp_t;
+typedef const __attribute__((address_space(1))) void* gbl_vp_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_p;
+__device__ uint4 g_attn_zero16 = {0u, 0u, 0u, 0u};
+
+template <int QT>
+__global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnArgs p, const float c_log2) {
+    using T = bf16;
+    constexpr int KT2 = 64, RB = 128, TILE_B = KT2 * RB, STAGE = 2 * TILE_B, DT = 4;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, lr = lane & 15;
+    const int H = p.H, W = p.W, nh = p.nh, hd = p.hd, dout = nh * hd;
+    const WinGeom G = make_geom(H, W, p.ws, p.pool);
+    const int h = blockIdx.y;
+    const int win = blockIdx.x % (G.nwy * G.nwx), n = blockIdx.x / (G.nwy * G.nwx);
+    const int wy = win / G.nwx, wx = win % G.nwx;
+    const int rh = min(G.qh, G.Ho - wy * G.qh), rw = min(G.qw, G.Wo - wx * G.qw);
+    const int nq = rh * rw, nk = G.wsh * G.wsw;
+    const int qbase = blockIdx.z * (64 * QT);
+    if (qbase >= nq) return;  // uniform for the workgroup, before any barrier
+
+    const T* __restrict__ qkv = static_cast<const T*>(p.qkv);
+    const T* __restrict__ bias_t = static_cast<const T*>(p.bias_t);
+    const size_t img_tok = (size_t)n * H * W;
+
+    // ---- Q fragments ----------------------------------------------------------------------------
+    bf16x8 qf[QT][2];
+    int qtok[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int qi = qbase + (wave * QT + qt) * 16 + lr;
+        const bool qv = qi < nq;
+        const int iy = qv ? qi / rw : 0, ix = qv ? qi % rw : 0;
+        qtok[qt] = qv ? (int)(((size_t)n * G.Ho + (wy * G.qh + iy)) * G.Wo + (wx * G.qw + ix)) : -1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int d0 = ks * 32 + g * 8;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            if (qv && d0 < hd) {
+                if (p.pool == 1) {
+                    const size_t tok = img_tok + (size_t)(wy * G.wsh + iy) * W + (wx * G.wsw + ix);
+                    load8f<T>(qkv + tok * p.ldqkv + h * hd + d0, v);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = -3.0e38f;
+                    for (int a = 0; a < p.pool; ++a)
+                        for (int b = 0; b < p.pool; ++b) {
+                            const int y = wy * G.wsh + iy * p.pool + a, x = wx * G.wsw + ix * p.pool + b;
+                            float t[8];
+                            if (y < H && x < W) load8f<T>(qkv + (img_tok + (size_t)y * W + x) * p.ldqkv + h * hd + d0, t);
+                            else load8f<T>(bias_t + h * hd + d0, t);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], t[j]);
+                        }
+                }
+            }
+            qf[qt][ks] = frag_from_f<T>(v);
+        }
+    }
+
+    // ---- DMA lane mapping: instruction j = wave + 4 i covers rows 8(j&7).. of K (j<8) or V (j>=8);
+    // a lane therefore touches two keys per tile (tile rows r0 and r0 + 32), whose window
+    // coordinates are advanced incrementally from tile to tile (no per-tile division).
+    const int lrow = lane >> 3, dsrc = ((lane & 7) ^ lrow) * 8;   // source d offset of this lane's chunk
+    const bool dok = dsrc < hd;
+    const int kstep_y = KT2 / G.wsw, kstep_x = KT2 % G.wsw;
+    int kky[2], kkx[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int kk = 8 * wave + lrow + 32 * e;
+        kky[e] = kk / G.wsw;
+        kkx[e] = kk - kky[e] * G.wsw;
+    }
+    auto issue = [&](int buf) {   // stages the tile the (kky, kkx) cursors point at, then advances them
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int y = wy * G.wsh + kky[e], x = wx * G.wsw + kkx[e];
+            const bool kin = kky[e] < G.wsh && dok;            // key index < nk
+            const bool real = y < H && x < W;
+            const size_t tokoff = (img_tok + (size_t)y * W + x) * p.ldqkv;
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int part = (v ? 2 * dout : dout) + h * hd + dsrc;
+                const void* src = &g_attn_zero16;
+                if (kin) src = real ? static_cast<const void*>(qkv + tokoff + part) : static_cast<const void*>(bias_t + part);
+                const int j = wave + 4 * e + 8 * v;
+                __builtin_amdgcn_global_load_lds((gbl_vp_t)src, (lds_vp_t)(smem + buf * STAGE + j * 1024), 16, 0, 0);
+            }
+            kky[e] += kstep_y;
+            kkx[e] += kstep_x;
+            if (kkx[e] >= G.wsw) { kkx[e] -= G.wsw; kky[e] += 1; }
+        }
+    };
+
+    f32x4 o[QT][DT];
+    float mrun[QT], lrun[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        mrun[qt] = -1.0e30f;
+        lrun[qt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int ntiles = (nk + KT2 - 1) / KT2;
+    issue(0);
+#pragma nounroll
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int buf = tile & 1;
+        __syncthreads();   // tile landed (vmcnt(0) + barrier); everyone is done with the other buffer
+        if (tile + 1 < ntiles) issue(buf ^ 1);
+        const char* kb = smem + buf * STAGE;
+        const char* vb = kb + TILE_B;
+        const bool tail = tile * KT2 + KT2 > nk;
+
+        bf16x8 kf[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int row = t * 16 + lr;
+                kf[t][ks] = *reinterpret_cast<const bf16x8*>(kb + row * RB + (swz(row, ks * 4 + g) << 4));
+            }
+        bf16x8 pf[QT][2];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            f32x4 s[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) mma16(kf[t][ks], qf[qt][ks], s[t]);
+            }
+            // online softmax on the RAW scores (scale folded into the exponent's fma); the O / l
+            // rescale only runs when some row's maximum actually moved (exact, not a threshold)
+            float mx = -1.0e30f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (tail && tile * KT2 + t * 16 + g * 4 + r >= nk) s[t][r] = -1.0e30f;
+                    mx = fmaxf(mx, s[t][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(mrun[qt], mx);
+            if (__any(mnew != mrun[qt])) {
+                const float alpha = __builtin_amdgcn_exp2f((mrun[qt] - mnew) * c_log2);
+                mrun[qt] = mnew;
+                lrun[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+            }
+            const float mneg = -mnew * c_log2;
+            float psum = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float pv[8];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(fmaf(s[2 * u + t][r], c_log2, mneg));
+                        pv[t * 4 + r] = e;
+                        psum += e;
+                    }
+                pf[qt][u] = frag_from_f<T>(pv);
+            }
+            lrun[qt] += psum;
+        }
+        // ---- O^T += V^T . P^T, V^T fragments by transposing LDS reads --------------------------
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int row = 32 * u + 4 * g + (lr >> 2), ch = 2 * dt + ((lr & 3) >> 1);
+                const char* a0 = vb + row * RB + (swz(row, ch) << 4) + (lr & 1) * 8;
+                const int row1 = row + 16;
+                const char* a1 = vb + row1 * RB + (swz(row1, ch) << 4) + (lr & 1) * 8;
+                const s16x4_t x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(a0));
+                const s16x4_t x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(a1));
+                const uint2 u0 = __builtin_bit_cast(uint2, x0), u1 = __builtin_bit_cast(uint2, x1);
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(u0.x, u0.y, u1.x, u1.y));
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) mma16(vf, pf[qt][u], o[qt][dt]);
+            }
+    }
+
+    T* __restrict__ out = static_cast<T*>(p.out);
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float l = lrun[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (qtok[qt] < 0) continue;
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d0 = dt * 16 + g * 4;
+            if (d0 < hd) store4(out + (size_t)qtok[qt] * p.ldo + h * hd + d0, o[qt][dt] * inv);
+        }
+        if (p.lse && g == 0)
+            p.lse[(size_t)qtok[qt] * nh + h] = (mrun[qt] * c_log2 + log2f(l)) * 0.69314718055994531f;
+    }
+}
+
+template <int QT> static int attn2_launch(const AttnArgs& a, int nqb, hipStream_t s) {
+    const WinGeom G = make_geom(a.H, a.W, a.ws, a.pool);
+    const float c = (1.0f / sqrtf((float)a.hd)) * 1.4426950408889634f;
+    const dim3 grid(a.N * G.nwy * G.nwx, a.nh, nqb), blk(256);
+    hipLaunchKernelGGL((attn2_fwd_kernel<QT>), grid, blk, 0, s, a, c);
+    LSAM_LAUNCH_CHECK();
+    return LSAM_OK;
+}
+
 template <typename T, int QT>
 static int attn_fwd_launch(const AttnArgs& a, int nwaves, int nqb, hipStream_t s) {
     const WinGeom G = make_geom(a.H, a.W, a.ws, a.pool);
@@ -286,6 +520,12 @@ template <typename T> int launch_attn_fwd(const AttnArgs& a, hipStream_t s) {
     LSAM_REQUIRE(a.nh <= 65535, LSAM_ERR_UNSUPPORTED, "attention: too many heads");
     const WinGeom G = make_geom(a.H, a.W, a.ws, a.pool);
     const int max_nq = G.qh * G.qw;
+    if constexpr (sizeof(T) == 2) {
+        if (a.bias_t && G.wsh * G.wsw >= 128 && max_nq >= 32 && a.ldqkv % 8 == 0) {
+            if (max_nq > 64) return attn2_launch<4>(a, cdiv(max_nq, 256), s);
+            return attn2_launch<1>(a, 1, s);
+        }
+    }
     if (max_nq > 64) {
         const int nwaves = min(4, cdiv(max_nq, 32));
         return attn_fwd_launch<T, 2>(a, nwaves, cdiv(max_nq, nwaves * 32), s);

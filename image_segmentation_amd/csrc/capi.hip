@@ -61,9 +61,9 @@ int lsam_layernorm_bwd(int dtype, const float* dy, int lddy, const float* x, int
                                  lddxt, M, C, s));
 }
 
-int lsam_attention_fwd(int dtype, const void* qkv, int ldqkv, const float* bias, void* out, int ldo, float* lse, int N,
-                       int H, int W, int ws, int pool, int nh, int hd, lsam_stream_t stream) {
-    AttnArgs a{qkv, ldqkv, bias, out, ldo, lse, N, H, W, ws, pool, nh, hd};
+int lsam_attention_fwd(int dtype, const void* qkv, int ldqkv, const float* bias, const void* bias_t, void* out, int ldo,
+                       float* lse, int N, int H, int W, int ws, int pool, int nh, int hd, lsam_stream_t stream) {
+    AttnArgs a{qkv, ldqkv, bias, out, ldo, lse, N, H, W, ws, pool, nh, hd, bias_t};
     hipStream_t s = static_cast<hipStream_t>(stream);
     DISPATCH(dtype, launch_attn_fwd<float>(a, s), launch_attn_fwd<bf16>(a, s));
 }

@@ -33,6 +33,7 @@ struct BlockGeom {
 struct BlockOff {
     size_t ln1w, ln1b, wqkv, bqkv, wproj, bproj, ln2w, ln2b, w1, b1, w2, b2, wsc, bsc;
     size_t wqkvT, wprojT, w1T, w2T, acat, bT;
+    size_t bqkvT;  // qkv bias in T (pad-token k/v source of the LDS-DMA attention kernel)
 };
 
 }  // namespace lsam
@@ -188,6 +189,7 @@ static int pack_t(lsam_hiera* h, const lsam_block_params_t* bp, const float* pat
         LSAM_TRY(vec(p.norm1_b, o.ln1b, d));
         LSAM_TRY(launch_pack_matrix<T>(p.qkv_w, d, 1, 3 * q, d, at<T>(arena, o.wqkv), g.kq, s));
         LSAM_TRY(vec(p.qkv_b, o.bqkv, 3 * q));
+        LSAM_TRY(launch_pack_matrix<T>(p.qkv_b, 0, 1, 1, 3 * q, at<T>(arena, o.bqkvT), 3 * q, s));
         LSAM_TRY(launch_pack_matrix<T>(p.attn_proj_w, q, 1, q, q, at<T>(arena, o.wproj), q, s));
         LSAM_TRY(vec(p.attn_proj_b, o.bproj, q));
         LSAM_TRY(vec(p.norm2_w, o.ln2w, q));
@@ -281,7 +283,7 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
         // ---- attention ------------------------------------------------------------------------------
         T* a = at<T>(ws, w.a);
         AttnArgs aa{qkv, 3 * q, at<float>(arena, o.bqkv), a, q, grad ? at<float>(ws, w.sv[gi].lse) : nullptr,
-                    N, g.gin, g.gin, g.ws, g.pool, g.heads, q / g.heads};
+                    N, g.gin, g.gin, g.ws, g.pool, g.heads, q / g.heads, at<T>(arena, o.bqkvT)};
         LSAM_TRY(launch_attn_fwd<T>(aa, s));
         // ---- proj + residual  (hieradet.py:79,163) -------------------------------------------------
         LSAM_TRY(linear<T>(a, q, at<T>(arena, o.wproj), q, at<float>(arena, o.bproj), res, q, 0, nullptr, 0, y, q,
@@ -465,6 +467,7 @@ int lsam_hiera_create(const lsam_hiera_config_t* c, lsam_hiera_t** out) {
         o.ln1b = b.take(d * 4);
         o.wqkv = b.take(3 * q * g.kq * e);
         o.bqkv = b.take(3 * q * 4);
+        o.bqkvT = b.take(3 * q * e);
         o.wproj = b.take(q * q * e);
         o.bproj = b.take(q * 4);
         o.ln2w = b.take(q * 4);

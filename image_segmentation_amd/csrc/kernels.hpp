@@ -36,6 +36,7 @@ struct AttnArgs {
     void* out; int ldo;
     float* lse;
     int N, H, W, ws, pool, nh, hd;
+    const void* bias_t;  // optional T-typed copy of bias (enables the LDS-DMA kernel)
 };
 template <typename T> int launch_attn_fwd(const AttnArgs& a, hipStream_t s);
 

@@ -102,7 +102,8 @@ def attention_fwd(qkv: torch.Tensor, bias: torch.Tensor, ws: int, pool: int, nh:
     Ho, Wo = H // pool, W // pool
     out = torch.empty(N, Ho, Wo, dout, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(N, Ho, Wo, nh, dtype=torch.float32, device=qkv.device) if want_lse else None
-    check(lib().lsam_attention_fwd(dtype_code(qkv.dtype), ptr(qkv), C3, ptr(bias), ptr(out), dout,
+    bias_t = bias.to(qkv.dtype) if qkv.dtype != torch.float32 else None   # dtype cast only (plumbing)
+    check(lib().lsam_attention_fwd(dtype_code(qkv.dtype), ptr(qkv), C3, ptr(bias), ptr(bias_t), ptr(out), dout,
                                    ptr(lse), N, H, W, ws, pool, nh, hd, stream()))
     return (out, lse) if want_lse else out
 

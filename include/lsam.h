@@ -96,12 +96,14 @@ int lsam_layernorm_bwd(int dtype, const float* dy, int lddy, const float* x, int
  *   qkv  T [N,H,W, 3*nh*hd]  channel order [q|k|v][head][hd]  (hieradet.py:59-61)
  *   bias fp32 [3*nh*hd]: value of qkv on the zero-pad tokens, which take part as keys
  *        (padding happens after LN1, hieradet.py:136,146)
+ *   bias_t (nullable) the same bias converted to T; when given (bf16), windows with >= 128 keys and
+ *        global attention use the LDS-DMA kernel, which fetches pad-token k/v from it
  *   ws   window size, 0 = global;  pool 1 or 2 (2x2 max over q inside each window)
  *   out  T [N, H/pool, W/pool, nh*hd];  lse (nullable) fp32 [N*(H/pool)*(W/pool)][nh]
  * hd % 8 == 0, hd <= 64. */
-int lsam_attention_fwd(int dtype, const void* qkv, int ldqkv, const float* bias, void* out, int ldo,
-                       float* lse, int N, int H, int W, int ws, int pool, int nh, int hd,
-                       lsam_stream_t stream);
+int lsam_attention_fwd(int dtype, const void* qkv, int ldqkv, const float* bias, const void* bias_t,
+                       void* out, int ldo, float* lse, int N, int H, int W, int ws, int pool, int nh,
+                       int hd, lsam_stream_t stream);
 
 /* Backward of the above for un-pooled windows with ws*ws <= 64 (the LoRA blocks):
  *   dout T [N,H,W,nh*hd] -> dqkv T [N,H,W, lddqkv] (q|k|v gradients of the real tokens; the
