@@ -390,11 +390,11 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnArgs p, con
 #pragma nounroll
     for (int tile = 0; tile < ntiles; ++tile) {
         const int buf = tile & 1;
-        __syncthreads();   // tile landed (vmcnt(0) + barrier); everyone is done with the other buffer
+        lds_dma_wait_barrier();   // tile landed (vmcnt(0) + barrier); everyone is done with the other buffer
         if (tile + 1 < ntiles) issue(buf ^ 1);
         const char* kb = smem + buf * STAGE;
         const char* vb = kb + TILE_B;
-        const bool tail = tile * KT2 + KT2 > nk;
+        const bool tail = __builtin_amdgcn_readfirstlane(tile * KT2 + KT2 > nk ? 1 : 0) != 0;
 
         bf16x8 kf[4][2];
 #pragma unroll
@@ -409,21 +409,22 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnArgs p, con
         for (int qt = 0; qt < QT; ++qt) {
             f32x4 s[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) mma16(kf[t][ks], qf[qt][ks], s[t]);
+            for (int t = 0; t < 4; ++t) {   // C = 0 goes in as the MFMA's inline constant: no zero-fill moves
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][0], qf[qt][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][1], qf[qt][1], s[t], 0, 0, 0);
             }
             // online softmax on the RAW scores (scale folded into the exponent's fma); the O / l
             // rescale only runs when some row's maximum actually moved (exact, not a threshold)
-            float mx = -1.0e30f;
+            if (tail) {   // block-uniform: only the last tile of a window pays for the key mask
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (tail && tile * KT2 + t * 16 + g * 4 + r >= nk) s[t][r] = -1.0e30f;
-                    mx = fmaxf(mx, s[t][r]);
-                }
+                    for (int r = 0; r < 4; ++r)
+                        if (tile * KT2 + t * 16 + g * 4 + r >= nk) s[t][r] = -1.0e30f;
+            }
+            float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+#pragma unroll
+            for (int t = 1; t < 4; ++t) mx = fmaxf(fmaxf(mx, s[t][0]), fmaxf(fmaxf(s[t][1], s[t][2]), s[t][3]));
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float mnew = fmaxf(mrun[qt], mx);

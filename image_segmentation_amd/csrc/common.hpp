@@ -144,4 +144,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// Barrier that publishes LDS written by LDS-DMA (buffer_load ... lds / global_load_lds): each wave
+// first waits for its OWN outstanding DMA (vmcnt(0)), then joins the barrier.  __syncthreads() alone
+// is not enough: hipcc does not count the LDS write of a DMA as something a workgroup release fence
+// has to wait for, and is free to place its vmcnt(0) AFTER the s_barrier (seen in the generated
+// code), which lets a wave read rows another wave's DMA has not landed yet.
+__device__ __forceinline__ void lds_dma_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 }  // namespace lsam

@@ -160,168 +160,295 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
 // 1 KiB = 8 rows x 128 B linearly, so the XOR swizzle is applied to the per-lane SOURCE address
 // (guide rule 21); out-of-range rows / k-chunks read a 16-byte zero word instead.
 // ---------------------------------------------------------------------------------------------
+#ifndef LSAM_ABL
+#define LSAM_ABL 0
+#endif
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 __device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
-template <typename T>
-__global__ __launch_bounds__(256, 3) void gemm2_kernel(const GemmArgs p) {
+//
+// WN = 1: 256 x 112 tile, 4 waves, one 46 KiB LDS stage, 3 workgroups per CU (used when N is an odd
+//         multiple of 112: the HBM-bound stage-1 shapes).
+// WN = 2: 256 x 224 tile, 8 waves (4 x 2), two 60 KiB LDS stages: the DMA of the next k-tile is
+//         issued right after the barrier that publishes the current one and lands while it is
+//         multiplied (one barrier per k-tile).
+// Both are PERSISTENT: a workgroup walks output tiles t = b, b + G, ...  The epilogue's stores are
+// fire-and-forget, so a tile's write-back (and, for WN = 2, the first k-tile DMA of the NEXT output
+// tile, issued before the epilogue) overlaps the next tile's main loop.  With one output tile per
+// workgroup every CU ran "all MFMA, then all stores" in lock-step and K <= 448 GEMMs spent ~70 % of
+// their time in that store phase.
+template <typename T, int WN, bool OUTF32>
+__global__ __launch_bounds__(256 * WN, 2) void gemm2_kernel(const GemmArgs p) {
     constexpr int EPC = Tr<T>::EPC, CPF = Tr<T>::CPF;
-    constexpr int MT = 4, NT = 7, BM = 256, BN = 112, ROWS = BM + BN;
+    constexpr int MT = 4, NT = 7, BM = 256, BN = 112 * WN, ROWS = BM + BN, NW = 4 * WN;
     constexpr int BK = 8 * EPC, KS = 8 / (4 * CPF);
-    constexpr int NINSTR = ROWS / 8;              // 46 DMA wave-instructions per k-tile
-    constexpr int PER_WAVE = (NINSTR + 3) / 4;    // 12
+    constexpr int A_IT = 32 / NW;                      // A: 32 DMA wave-instructions per k-tile
+    constexpr int W_INSTR = BN / 8, W_IT = (W_INSTR + NW - 1) / NW;
+    constexpr int STAGE = ROWS * 128;
     using frag = typename Tr<T>::frag;
 
-    __shared__ __attribute__((aligned(1024))) char smem[ROWS * 128];
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
     const int g = lane >> 4, lr = lane & 15;
     const int M = p.M, N = p.N, K = p.K;
-    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
-    const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int m0 = (id / tiles_n) * BM, n0 = (id % tiles_n) * BN;
+    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
+    const int G = gridDim.x;
+    const int slot = xcd_remap(blockIdx.x, G);   // consecutive slots (same A rows) share an XCD's L2
     const T* __restrict__ A = static_cast<const T*>(p.A);
     const T* __restrict__ Wt = static_cast<const T*>(p.W);
 
-    // per-lane DMA sources: instruction j = wave + 4 i covers tile rows 8j .. 8j+7; i < 8 are the A
-    // rows (j < 32), i >= 8 the W rows, so consecutive i are 32 rows apart in the same matrix.
+    // per-lane DMA sources: A instruction j = wave + NW i covers A-tile rows 8j .. 8j+7 (j < 32),
+    // W instruction j likewise for the W tile, so consecutive i are 8 NW rows apart.
     // Buffer addressing: 32-bit byte offsets, and the hardware range check turns every
     // out-of-range row / k-chunk (offset forced to 0xFFFFFFFF) into zeros.
     const int lrow = lane >> 3, ck = ((lane & 7) ^ lrow) * EPC;   // source k offset of this lane's chunk
-    const int arow0 = m0 + 8 * wave + lrow, wrow0 = n0 + 8 * wave + lrow;
-    const unsigned aoff0 = ((unsigned)arow0 * (unsigned)p.lda + ck) * (unsigned)sizeof(T);
-    const unsigned woff0 = ((unsigned)wrow0 * (unsigned)p.ldw + ck) * (unsigned)sizeof(T);
-    const unsigned astep = 32u * (unsigned)p.lda * (unsigned)sizeof(T), wstep = 32u * (unsigned)p.ldw * (unsigned)sizeof(T);
+    const unsigned astep = 8u * NW * (unsigned)p.lda * (unsigned)sizeof(T), wstep = 8u * NW * (unsigned)p.ldw * (unsigned)sizeof(T);
     const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(A), 0,
                                                          (int)(((size_t)(M - 1) * p.lda + K) * sizeof(T)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Wt), 0,
                                                          (int)(((size_t)(N - 1) * p.ldw + K) * sizeof(T)), 0x00020000);
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    auto read_frag = [&](int row, int c0) -> frag {
-        const uint4 x0 = *reinterpret_cast<const uint4*>(smem + row * 128 + (swz(row, c0) << 4));
+    struct TileAddr { int m0, n0, arow0, wrow0; unsigned aoff0, woff0; };
+    auto tile_addr = [&](int t) {
+        TileAddr a;
+        a.m0 = (t / tiles_n) * BM;
+        a.n0 = (t % tiles_n) * BN;
+        a.arow0 = a.m0 + 8 * wave + lrow;
+        a.wrow0 = a.n0 + 8 * wave + lrow;
+        a.aoff0 = ((unsigned)a.arow0 * (unsigned)p.lda + ck) * (unsigned)sizeof(T);
+        a.woff0 = ((unsigned)a.wrow0 * (unsigned)p.ldw + ck) * (unsigned)sizeof(T);
+        return a;
+    };
+    auto read_frag = [&](const char* base, int row, int c0) -> frag {
+        const uint4 x0 = *reinterpret_cast<const uint4*>(base + row * 128 + (swz(row, c0) << 4));
         uint4 x1 = x0;
-        if constexpr (CPF == 2) x1 = *reinterpret_cast<const uint4*>(smem + row * 128 + (swz(row, c0 + 1) << 4));
+        if constexpr (CPF == 2) x1 = *reinterpret_cast<const uint4*>(base + row * 128 + (swz(row, c0 + 1) << 4));
         return make_frag(x0, x1, T{});
     };
-
-    const int nkt = (K + BK - 1) / BK;
-#pragma nounroll
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (kt > 0) __syncthreads();   // every wave has finished reading the previous tile
+    auto issue = [&](const TileAddr& ta, int kt, int buf) {
+#if LSAM_ABL & 1
+        return;
+#endif
         const int k0 = kt * BK;
         const bool kok = k0 + ck < K;
         const unsigned kb = (unsigned)k0 * (unsigned)sizeof(T);
+        char* base = smem + buf * STAGE;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const unsigned vo = (arow0 + 32 * i < M && kok) ? aoff0 + i * astep + kb : 0xFFFFFFFFu;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_ptr_t)(smem + (wave + 4 * i) * 1024), 16, vo, 0, 0, 0);
+        for (int i = 0; i < A_IT; ++i) {
+            const unsigned vo = (ta.arow0 + 8 * NW * i < M && kok) ? ta.aoff0 + i * astep + kb : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_ptr_t)(base + (wave + NW * i) * 1024), 16, vo, 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < PER_WAVE - 8; ++i) {
-            const int j = 32 + wave + 4 * i;
-            if (j < NINSTR) {
-                const unsigned vo = (wrow0 + 32 * i < N && kok) ? woff0 + i * wstep + kb : 0xFFFFFFFFu;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(smem + j * 1024), 16, vo, 0, 0, 0);
+        for (int i = 0; i < W_IT; ++i) {
+            const int j = wave + NW * i;
+            if (j < W_INSTR) {
+                const unsigned vo = (ta.wrow0 + 8 * NW * i < N && kok) ? ta.woff0 + i * wstep + kb : 0xFFFFFFFFu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(base + (32 + j) * 1024), 16, vo, 0, 0, 0);
             }
         }
-        __syncthreads();               // DMA landed (vmcnt(0)) and visible to all waves
+    };
+
+    f32x4 acc[MT][NT];
+    // All fragment reads of a k-tile (bf16: 22 ds_read_b128 per lane) are issued before its first MFMA,
+    // and (WN = 2) before the DMA of the next k-tile: hipcc drains vmcnt(0) in front of any LDS read
+    // that follows an LDS-DMA in program order, so reads placed after the DMA would serialise copy
+    // and multiply.  The MFMAs then wait on counted lgkmcnt(N) as the reads return in order.
+    auto load_frags = [&](int buf, frag (&af)[KS][MT], frag (&wf)[KS][NT]) {
+        const char* base = smem + buf * STAGE;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int c0 = (ks * 4 + g) * CPF;
-            frag af[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) af[mt] = read_frag(wave * 64 + mt * 16 + lr, c0);
+            for (int mt = 0; mt < MT; ++mt) af[ks][mt] = read_frag(base, wm * 64 + mt * 16 + lr, c0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[ks][nt] = read_frag(base, BM + wn * 112 + nt * 16 + lr, c0);
+        }
+    };
+    // fp32 fragments are twice as wide (8 VGPRs): hoisting all of them would spill, so the fp32 path
+    // (accuracy path, not the benchmarked one) reads one W fragment per 4 MFMAs.
+    auto compute_interleaved = [&](int buf) {
+        const char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int c0 = (ks * 4 + g) * CPF;
+            frag a4[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a4[mt] = read_frag(base, wm * 64 + mt * 16 + lr, c0);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const frag wf = read_frag(BM + nt * 16 + lr, c0);
+                const frag w1 = read_frag(base, BM + wn * 112 + nt * 16 + lr, c0);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) mma16(wf, af[mt], acc[mt][nt]);
+                for (int mt = 0; mt < MT; ++mt) mma16(w1, a4[mt], acc[mt][nt]);
             }
         }
-    }
+    };
+    auto mfmas = [&](const frag (&af)[KS][MT], const frag (&wf)[KS][NT]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) mma16(wf[ks][nt], af[ks][mt], acc[mt][nt]);
+    };
 
     // ---- epilogue.  Lane (lr, g) holds C[m][16 nt + 4 g .. +3].  fp32 results go out as 16-byte
-    // stores (64 contiguous bytes per row and instruction).  For bf16 results the natural 8-byte
-    // store leaves 32-byte row fragments, which the memory system handles at ~1 TB/s; instead two
-    // neighbouring column tiles are regrouped across the four lanes of a row with
-    // v_permlane32_swap + v_permlane16_swap so every lane stores 16 bytes = 8 consecutive columns.
+    // stores (64 contiguous bytes per row and instruction).  For bf16 results two neighbouring
+    // column tiles are regrouped across the four lanes of a row with v_permlane32_swap +
+    // v_permlane16_swap so every lane stores 16 bytes = 8 consecutive columns.
+    // The global reads of the epilogue are batched: the 7 residual / GELU-backward operands of a
+    // 16-row block are requested in one go (one memory round trip per row block instead of one per
+    // 16 x 16 tile); the bias is already in the accumulators (init_acc).
     const int flags = p.flags;
-    const bool out_f32 = (flags & LSAM_EPI_OUT_F32) || sizeof(T) == 4;
-    auto finish = [&](f32x4 v, int m, size_t rm, int n, f32x4& pre) {
-        if (p.bias) v += load4(p.bias + n);
-        pre = v;
-        if (flags & LSAM_EPI_GELU) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_t<sizeof(T) == 2>(v[r]);
+    constexpr bool out_f32 = OUTF32 || sizeof(T) == 4;
+    const int lr_c = lr, g_c = g;
+    auto epilogue = [&](int m0, int n0) {
+        // opaque per-tile copies of the lane coordinates: keeps the compiler from hoisting the 28
+        // tiles' worth of lane-constant address arithmetic out of the persistent tile loop (which
+        // costs > 100 VGPRs and spills the accumulators)
+        int lr = lr_c, g = g_c;
+        asm volatile("" : "+v"(lr), "+v"(g));
+#if LSAM_ABL & 4
+        {
+            float sacc = 0.f;
+            for (int i = 0; i < MT; ++i) for (int j = 0; j < NT; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+            if (sacc != 1.2345e-30f) return;
         }
-        if (flags & LSAM_EPI_GELU_BWD) {
-            const f32x4 x = load4(static_cast<const T*>(p.aux) + (size_t)m * p.ldaux + n);
+#endif
+        const int nc = n0 + wn * 112 + 4 * g;          // this lane's column in column tile 0
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_t<sizeof(T) == 2>(x[r]);
-        }
-        if (p.res) v += load4(p.res + rm * p.ldres + n);
-        return v;
-    };
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = m0 + wave * 64 + mt * 16 + lr;
-        const bool mok = m < M;
-        const int mc = mok ? m : M - 1;   // clamp: every lane stays active for the cross-lane swaps
-        const size_t rm = p.res_row_mod > 0 ? (size_t)(mc % p.res_row_mod) : (size_t)mc;
-        if (out_f32) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int n = n0 + nt * 16 + 4 * g;
-                f32x4 pre;
-                const f32x4 v = finish(acc[mt][nt], mc, rm, n, pre);
-                if (!mok) continue;
-                if (flags & LSAM_EPI_SAVE_PRE) store4(static_cast<T*>(p.out2) + (size_t)m * p.ldo2 + n, pre);
-                store4(static_cast<float*>(p.out) + (size_t)m * p.ldo + n, v);
-            }
-        } else {
-            if constexpr (sizeof(T) == 2) {
-                auto pack2 = [](const f32x4& v) -> uint2 {
-                    bf16x4 o;
-                    o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
-                    return __builtin_bit_cast(uint2, o);
-                };
-                auto store_pair = [&](bf16* base, int ld, uint2 x, uint2 y, int ncol0) {
-                    auto r0 = __builtin_amdgcn_permlane32_swap(x.x, y.x, false, false);
-                    auto r1 = __builtin_amdgcn_permlane32_swap(x.y, y.y, false, false);
-                    auto q0 = __builtin_amdgcn_permlane16_swap(r0[0], r0[1], false, false);
-                    auto q1 = __builtin_amdgcn_permlane16_swap(r1[0], r1[1], false, false);
-                    if (mok)
-                        *reinterpret_cast<uint4*>(base + (size_t)m * ld + ncol0 + 8 * g) =
-                            make_uint4(q0[0], q1[0], q0[1], q1[1]);
-                };
-#pragma unroll
-                for (int nt = 0; nt + 1 < NT; nt += 2) {
-                    f32x4 pa, pb;
-                    const f32x4 va = finish(acc[mt][nt], mc, rm, n0 + nt * 16 + 4 * g, pa);
-                    const f32x4 vb = finish(acc[mt][nt + 1], mc, rm, n0 + (nt + 1) * 16 + 4 * g, pb);
-                    if (flags & LSAM_EPI_SAVE_PRE)
-                        store_pair(static_cast<bf16*>(p.out2), p.ldo2, pack2(pa), pack2(pb), n0 + nt * 16);
-                    store_pair(static_cast<bf16*>(p.out), p.ldo, pack2(va), pack2(vb), n0 + nt * 16);
-                }
-                {
-                    constexpr int nt = NT - 1;
-                    const int n = n0 + nt * 16 + 4 * g;
-                    f32x4 pre;
-                    const f32x4 v = finish(acc[mt][nt], mc, rm, n, pre);
+        for (int mt = 0; mt < MT; ++mt) {
+            __builtin_amdgcn_sched_barrier(0);   // bound the scheduler's load hoisting: one row block at a time
+            const int m = m0 + wm * 64 + mt * 16 + lr;
+            const bool mok = m < M;
+            const int mc = mok ? m : M - 1;   // clamp: every lane stays active for the cross-lane swaps
+            auto pack2 = [](const f32x4& v) -> uint2 {
+                bf16x4 o;
+                o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
+                return __builtin_bit_cast(uint2, o);
+            };
+            auto store_row = [&](auto* base, int ld, const f32x4 (&val)[NT]) {
+                auto* rowp = base + (size_t)m * ld + n0 + wn * 112;
+                if constexpr (sizeof(*base) == 4) {
                     if (mok) {
-                        if (flags & LSAM_EPI_SAVE_PRE) store4(static_cast<T*>(p.out2) + (size_t)m * p.ldo2 + n, pre);
-                        store4(static_cast<T*>(p.out) + (size_t)m * p.ldo + n, v);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) store4(rowp + nt * 16 + 4 * g, val[nt]);
                     }
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt + 1 < NT; nt += 2) {
+                        const uint2 x = pack2(val[nt]), y = pack2(val[nt + 1]);
+                        auto r0 = __builtin_amdgcn_permlane32_swap(x.x, y.x, false, false);
+                        auto r1 = __builtin_amdgcn_permlane32_swap(x.y, y.y, false, false);
+                        auto q0 = __builtin_amdgcn_permlane16_swap(r0[0], r0[1], false, false);
+                        auto q1 = __builtin_amdgcn_permlane16_swap(r1[0], r1[1], false, false);
+                        if (mok) *reinterpret_cast<uint4*>(rowp + nt * 16 + 8 * g) = make_uint4(q0[0], q1[0], q0[1], q1[1]);
+                    }
+                    if (mok) store4(rowp + (NT - 1) * 16 + 4 * g, val[NT - 1]);
                 }
+            };
+            f32x4 rv[NT], v[NT];
+            if (p.res) {
+                const float* rp = p.res + (p.res_row_mod > 0 ? (size_t)(mc % p.res_row_mod) : (size_t)mc) * p.ldres + nc;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) rv[nt] = load4(rp + 16 * nt);
             }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) v[nt] = acc[mt][nt];
+            if (flags & LSAM_EPI_SAVE_PRE) store_row(static_cast<T*>(p.out2), p.ldo2, v);
+            if (flags & LSAM_EPI_GELU) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[nt][r] = gelu_t<sizeof(T) == 2>(v[nt][r]);
+            }
+            if (flags & LSAM_EPI_GELU_BWD) {
+                const T* xp = static_cast<const T*>(p.aux) + (size_t)mc * p.ldaux + nc;
+                f32x4 x[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) x[nt] = load4(xp + 16 * nt);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[nt][r] *= gelu_grad_t<sizeof(T) == 2>(x[nt][r]);
+            }
+            if (p.res) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) v[nt] += rv[nt];
+            }
+            if constexpr (out_f32) store_row(static_cast<float*>(p.out), p.ldo, v);
+            else store_row(static_cast<bf16*>(p.out), p.ldo, v);
+        }
+    };
+    // the accumulators start at the bias (one batched read per output tile) instead of zero
+    auto init_acc = [&](int n0) {
+        f32x4 bv[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = load4(p.bias + n0 + wn * 112 + 4 * g + 16 * nt);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = bv[j];
+    };
+
+    const int nkt = (K + BK - 1) / BK;
+    constexpr bool HOIST = sizeof(T) == 2;
+    frag af[HOIST ? KS : 1][HOIST ? MT : 1], wf[HOIST ? KS : 1][HOIST ? NT : 1];
+    if constexpr (WN == 1) {
+        for (int t = slot; t < ntiles; t += G) {
+            const TileAddr ta = tile_addr(t);
+            init_acc(ta.n0);
+#pragma nounroll
+            for (int kt = 0; kt < nkt; ++kt) {
+                __syncthreads();           // every wave has finished reading the previous k-tile
+                issue(ta, kt, 0);
+                lds_dma_wait_barrier();    // DMA landed (vmcnt(0)) and visible to all waves
+#if !(LSAM_ABL & 2)
+                if constexpr (HOIST) {
+                    load_frags(0, af, wf);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfmas(af, wf);
+                } else {
+                    compute_interleaved(0);
+                }
+#endif
+            }
+            epilogue(ta.m0, ta.n0);
+        }
+    } else {
+        int st = 0;                        // LDS stage holding the k-tile about to be consumed
+        int t = slot;
+        TileAddr ta = tile_addr(t < ntiles ? t : 0);
+        if (t < ntiles) issue(ta, 0, 0);
+        while (t < ntiles) {
+            const int tn = t + G;
+            const TileAddr tb = tile_addr(tn < ntiles ? tn : 0);
+            init_acc(ta.n0);
+#pragma nounroll
+            for (int kt = 0; kt < nkt; ++kt) {
+                lds_dma_wait_barrier();    // k-tile landed; every wave is done with the other stage
+#if !(LSAM_ABL & 2)
+                if constexpr (HOIST) load_frags(st, af, wf);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt + 1 < nkt) issue(ta, kt + 1, st ^ 1);
+                else if (tn < ntiles) issue(tb, 0, st ^ 1);   // next output tile's first k-tile
+                __builtin_amdgcn_sched_barrier(0);
+#if !(LSAM_ABL & 2)
+                if constexpr (HOIST) mfmas(af, wf);
+                else compute_interleaved(st);
+#endif
+                st ^= 1;
+            }
+            epilogue(ta.m0, ta.n0);
+            ta = tb;
+            t = tn;
         }
     }
 }
@@ -390,16 +517,25 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     return LSAM_OK;
 }
 
-template <typename T> static int launch_v2(const GemmArgs& a, hipStream_t s) {
-    const int nblk = cdiv(a.M, 256) * cdiv(a.N, 112);
+template <typename T, int WN, bool OUTF32> static int launch_v2(const GemmArgs& a, hipStream_t s) {
+    constexpr int LDS = WN * (256 + 112 * WN) * 128;
+    auto kern = gemm2_kernel<T, WN, OUTF32>;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        LSAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    const int ntiles = cdiv(a.M, 256) * cdiv(a.N, 112 * WN);
+    constexpr int PER_CU = WN == 1 ? 2 : 1;
+    const int nblk = ntiles < 256 * PER_CU ? ntiles : 256 * PER_CU;   // persistent: one wave of workgroups
     const bool prof = g_prof_on && g_prof_n < g_prof_cap;
     if (prof) LSAM_HIP(hipEventRecord(g_prof[g_prof_n].e0, s));
-    hipLaunchKernelGGL(gemm2_kernel<T>, dim3(nblk), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256 * WN), LDS, s, a);
     LSAM_LAUNCH_CHECK();
     if (prof) {
         LSAM_HIP(hipEventRecord(g_prof[g_prof_n].e1, s));
         g_prof[g_prof_n].flops = 2.0 * a.M * a.N * a.K;
-        g_prof[g_prof_n].cfg = (int)sizeof(T) * 1000 + 112;
+        g_prof[g_prof_n].cfg = (int)sizeof(T) * 1000 + 112 * WN;
         g_prof[g_prof_n].m = a.M; g_prof[g_prof_n].n = a.N; g_prof[g_prof_n].k = a.K;
         ++g_prof_n;
     }
@@ -424,7 +560,11 @@ template <typename T> int launch_gemm(const GemmArgs& a, hipStream_t s) {
                  "linear: SAVE_PRE needs out2");
     if (a.N % 112 == 0 && (double)a.M * a.lda * sizeof(T) < 2.0e9 && (double)a.N * a.ldw * sizeof(T) < 2.0e9 && a.M >= 1024 &&
         a.ldo % 8 == 0 && (!(a.flags & LSAM_EPI_SAVE_PRE) || (a.ldo2 % 8 == 0 && aligned16(a.out2))))
-        return launch_v2<T>(a, s);
+    {
+        const bool of32 = (a.flags & LSAM_EPI_OUT_F32) || sizeof(T) == 4;
+        if (a.N % 224 == 0) return of32 ? launch_v2<T, 2, true>(a, s) : launch_v2<T, 2, sizeof(T) == 4>(a, s);
+        return of32 ? launch_v2<T, 1, true>(a, s) : launch_v2<T, 1, sizeof(T) == 4>(a, s);
+    }
     if (a.N % 112 == 0) return launch_cfg<T, 2, 7, 4, 1>(a, s);
     return launch_cfg<T, 4, 4, 2, 2>(a, s);
 }
