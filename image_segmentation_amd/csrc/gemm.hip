@@ -535,7 +535,7 @@ template <typename T, int WN, bool OUTF32> static int launch_v2(const GemmArgs& 
     if (prof) {
         LSAM_HIP(hipEventRecord(g_prof[g_prof_n].e1, s));
         g_prof[g_prof_n].flops = 2.0 * a.M * a.N * a.K;
-        g_prof[g_prof_n].cfg = (int)sizeof(T) * 1000 + 112 * WN;
+        g_prof[g_prof_n].cfg = (int)sizeof(T) * 1000 + 112 * WN + (OUTF32 && sizeof(T) == 2 ? 1 : 0);
         g_prof[g_prof_n].m = a.M; g_prof[g_prof_n].n = a.N; g_prof[g_prof_n].k = a.K;
         ++g_prof_n;
     }
