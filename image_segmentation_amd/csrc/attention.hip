@@ -705,6 +705,213 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdArgs p, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 MFMA backward.  One WAVE per (window, head); a workgroup is 4 heads of one window and uses
+// no workgroup barrier: every wave stages its own Q, K, V, dO tiles ([64 rows][64 d] bf16, 128-byte
+// rows, chunk-XOR swizzle) in a private 32 KiB slice of LDS and reads them back as MFMA operands:
+//   S^T = K Q^T, dP^T = V dO^T      (lane owns one query)  -> delta_i, dS^T -> dQ^T = K^T dS^T
+//   S   = Q K^T, dP   = dO V^T      (lane owns one key)    -> P, dS        -> dV^T = dO^T P, dK^T = Q^T dS
+// The scores are recomputed in both orientations (cheap: the kernel is bound by its ~200 MB of
+// global traffic, not by its 224 MFMAs per head-window) so that P / dS always leave the MFMA in the
+// register layout the next product wants as its B operand; the A operands K^T, dO^T, Q^T come out
+// of the row-major tiles through the transposing LDS read ds_read_b64_tr_b16.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const AttnBwdArgs p, const float scale, const float c_log2) {
+    using T = bf16;
+    constexpr int RB = 128, TILE_B = 64 * RB, WAVE_B = 4 * TILE_B + 512;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, lr = lane & 15;
+    const int h = blockIdx.y * 4 + wave;
+    if (h >= p.nh) return;   // wave-uniform; the kernel has no workgroup barrier
+
+    char* qb = smem + wave * WAVE_B;
+    char* kb = qb + TILE_B;
+    char* vb = kb + TILE_B;
+    char* ob = vb + TILE_B;
+    float* lse_s = reinterpret_cast<float*>(ob + TILE_B);
+    float* del_s = lse_s + 64;
+
+    const int H = p.H, W = p.W, nh = p.nh, hd = p.hd, dout = nh * hd, ws = p.ws;
+    const int nwy = (H + ws - 1) / ws, nwx = (W + ws - 1) / ws;
+    const int win = blockIdx.x % (nwy * nwx), n = blockIdx.x / (nwy * nwx);
+    const int wy = win / nwx, wx = win % nwx;
+    const int rh = min(ws, H - wy * ws), rw = min(ws, W - wx * ws);
+    const int nq = rh * rw, nk = ws * ws;
+    const T* __restrict__ qkv = static_cast<const T*>(p.qkv);
+    const T* __restrict__ dO = static_cast<const T*>(p.dout);
+    const size_t img_tok = (size_t)n * H * W;
+
+    // lane l describes row l of the tiles: query token, key token (-1 = pad key, -2 = no key)
+    int qtok_l = -1, ktok_l = -2;
+    if (lane < nq) qtok_l = (int)(img_tok + (size_t)(wy * ws + lane / rw) * W + (wx * ws + lane % rw));
+    if (lane < nk) {
+        const int y = wy * ws + lane / ws, x = wx * ws + lane % ws;
+        ktok_l = (y < H && x < W) ? (int)(img_tok + (size_t)y * W + x) : -1;
+    }
+    lse_s[lane] = qtok_l >= 0 ? p.lse[(size_t)qtok_l * nh + h] * 1.4426950408889634f : 0.f;
+
+    // ---- stage the four tiles --------------------------------------------------------------------
+    {
+        const int ch = lane & 7, d0 = ch * 8;
+        auto pack_bias = [&](const float* b) -> uint4 {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = b[j];
+            return __builtin_bit_cast(uint4, frag_from_f<T>(v));
+        };
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int row = 8 * c + (lane >> 3);
+            const int qt = __shfl(qtok_l, row, 64), kt = __shfl(ktok_l, row, 64);
+            uint4 q = make_uint4(0u, 0u, 0u, 0u), dv = q, k = q, v = q;
+            if (d0 < hd) {
+                if (qt >= 0) {
+                    q = *reinterpret_cast<const uint4*>(qkv + (size_t)qt * p.ldqkv + h * hd + d0);
+                    dv = *reinterpret_cast<const uint4*>(dO + (size_t)qt * p.lddo + h * hd + d0);
+                }
+                if (kt >= 0) {
+                    k = *reinterpret_cast<const uint4*>(qkv + (size_t)kt * p.ldqkv + dout + h * hd + d0);
+                    v = *reinterpret_cast<const uint4*>(qkv + (size_t)kt * p.ldqkv + 2 * dout + h * hd + d0);
+                } else if (kt == -1) {
+                    k = pack_bias(p.bias + dout + h * hd + d0);
+                    v = pack_bias(p.bias + 2 * dout + h * hd + d0);
+                }
+            }
+            const int off = row * RB + (swz(row, ch) << 4);
+            *reinterpret_cast<uint4*>(qb + off) = q;
+            *reinterpret_cast<uint4*>(ob + off) = dv;
+            *reinterpret_cast<uint4*>(kb + off) = k;
+            *reinterpret_cast<uint4*>(vb + off) = v;
+        }
+    }
+
+    auto row_frag = [&](const char* base, int t, int ks) -> bf16x8 {
+        const int row = t * 16 + lr;
+        return *reinterpret_cast<const bf16x8*>(base + row * RB + (swz(row, ks * 4 + g) << 4));
+    };
+    // A operand X^T[d = 16 dt + ..][k-slot]: slot 8g + 4t + r <-> tile row 32 u + 16 t + 4 g + r
+    auto tr_frag = [&](const char* base, int u, int dt) -> bf16x8 {
+        const int row = 32 * u + 4 * g + (lr >> 2), ch = 2 * dt + ((lr & 3) >> 1);
+        const char* a0 = base + row * RB + (swz(row, ch) << 4) + (lr & 1) * 8;
+        const int row1 = row + 16;
+        const char* a1 = base + row1 * RB + (swz(row1, ch) << 4) + (lr & 1) * 8;
+        const s16x4_t x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(a0));
+        const s16x4_t x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(a1));
+        const uint2 u0 = __builtin_bit_cast(uint2, x0), u1 = __builtin_bit_cast(uint2, x1);
+        return __builtin_bit_cast(bf16x8, make_uint4(u0.x, u0.y, u1.x, u1.y));
+    };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    T* __restrict__ dqkv = static_cast<T*>(p.dqkv);
+
+    // ---- pass 1: lane owns query i = 16 it + lr.  delta_i, dS^T, dQ --------------------------------
+#pragma unroll 1
+    for (int it = 0; it < 4; ++it) {
+        if (it * 16 >= nq) {   // wave-uniform: no query in this tile
+            if (g == 0) del_s[it * 16 + lr] = 0.f;
+            continue;
+        }
+        const bf16x8 qf0 = row_frag(qb, it, 0), qf1 = row_frag(qb, it, 1);
+        const bf16x8 of0 = row_frag(ob, it, 0), of1 = row_frag(ob, it, 1);
+        const int i = it * 16 + lr;
+        const float lse2 = lse_s[i];
+        float pr[4][4], dpv[4][4];
+        float delta = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(kb, jt, 0), qf0, zero4, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(kb, jt, 1), qf1, s, 0, 0, 0);
+            f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(vb, jt, 0), of0, zero4, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(vb, jt, 1), of1, dp, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = jt * 16 + 4 * g + r;
+                const float e = (i < nq && j < nk) ? __builtin_amdgcn_exp2f(fmaf(s[r], c_log2, -lse2)) : 0.f;
+                pr[jt][r] = e;
+                dpv[jt][r] = dp[r];
+                delta = fmaf(e, dp[r], delta);
+            }
+        }
+        delta += __shfl_xor(delta, 16, 64);
+        delta += __shfl_xor(delta, 32, 64);
+        if (g == 0) del_s[i] = delta;
+        bf16x8 dsf[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float v[8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[t * 4 + r] = pr[2 * u + t][r] * (dpv[2 * u + t][r] - delta) * scale;
+            dsf[u] = frag_from_f<T>(v);
+        }
+        const int tokq = __shfl(qtok_l, i, 64);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            f32x4 acc = zero4;
+            mma16(tr_frag(kb, 0, dt), dsf[0], acc);
+            mma16(tr_frag(kb, 1, dt), dsf[1], acc);
+            const int d0 = dt * 16 + 4 * g;
+            if (tokq >= 0 && d0 < hd) store4(dqkv + (size_t)tokq * p.lddqkv + h * hd + d0, acc);
+        }
+    }
+
+    // ---- pass 2: lane owns key j = 16 jt + lr.  P, dS -> dV, dK ------------------------------------
+#pragma unroll 1
+    for (int jt = 0; jt < 4; ++jt) {
+        if (jt * 16 >= nk) break;   // wave-uniform
+        const bf16x8 kf0 = row_frag(kb, jt, 0), kf1 = row_frag(kb, jt, 1);
+        const bf16x8 vf0 = row_frag(vb, jt, 0), vf1 = row_frag(vb, jt, 1);
+        const int j = jt * 16 + lr;
+        float pr[4][4], dsv[4][4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(qb, it, 0), kf0, zero4, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(qb, it, 1), kf1, s, 0, 0, 0);
+            f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(ob, it, 0), vf0, zero4, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(ob, it, 1), vf1, dp, 0, 0, 0);
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + it * 16 + 4 * g);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + it * 16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = it * 16 + 4 * g + r;
+                const float e = (i < nq && j < nk) ? __builtin_amdgcn_exp2f(fmaf(s[r], c_log2, -l4[r])) : 0.f;
+                pr[it][r] = e;
+                dsv[it][r] = e * (dp[r] - d4[r]) * scale;
+            }
+        }
+        bf16x8 pf[2], dsf[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float a[8], b[8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    a[t * 4 + r] = pr[2 * u + t][r];
+                    b[t * 4 + r] = dsv[2 * u + t][r];
+                }
+            pf[u] = frag_from_f<T>(a);
+            dsf[u] = frag_from_f<T>(b);
+        }
+        const int tokk = __shfl(ktok_l, j, 64);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            f32x4 av = zero4, ak = zero4;
+            mma16(tr_frag(ob, 0, dt), pf[0], av);
+            mma16(tr_frag(ob, 1, dt), pf[1], av);
+            mma16(tr_frag(qb, 0, dt), dsf[0], ak);
+            mma16(tr_frag(qb, 1, dt), dsf[1], ak);
+            const int d0 = dt * 16 + 4 * g;
+            if (tokk >= 0 && d0 < hd) {
+                store4(dqkv + (size_t)tokk * p.lddqkv + dout + h * hd + d0, ak);
+                store4(dqkv + (size_t)tokk * p.lddqkv + 2 * dout + h * hd + d0, av);
+            }
+        }
+    }
+}
+
 template <typename T> int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t s) {
     LSAM_REQUIRE(a.qkv && a.bias && a.dout && a.lse && a.dqkv, LSAM_ERR_BAD_ARG, "attention_bwd: null pointer");
     LSAM_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.nh > 0, LSAM_ERR_BAD_ARG, "attention_bwd: empty shape");
@@ -713,12 +920,30 @@ template <typename T> int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t s) {
     LSAM_REQUIRE(a.hd > 0 && a.hd <= 64, LSAM_ERR_UNSUPPORTED, "attention_bwd: head_dim %d", a.hd);
     LSAM_REQUIRE(a.ldqkv >= 3 * a.nh * a.hd && a.lddqkv >= 3 * a.nh * a.hd && a.lddo >= a.nh * a.hd,
                  LSAM_ERR_BAD_ARG, "attention_bwd: leading dimensions");
+    const int nwy = cdiv(a.H, a.ws), nwx = cdiv(a.W, a.ws);
+    if constexpr (sizeof(T) == 2) {
+        const bool al16 = ((reinterpret_cast<uintptr_t>(a.qkv) | reinterpret_cast<uintptr_t>(a.dout)) & 15) == 0;
+        if (a.hd % 8 == 0 && a.ldqkv % 8 == 0 && a.lddo % 8 == 0 && a.lddqkv % 4 == 0 && al16 &&
+            (reinterpret_cast<uintptr_t>(a.dqkv) & 7) == 0) {
+            constexpr int LDSB = 4 * (4 * 64 * 128 + 512);
+            static thread_local bool attr_set = false;
+            if (!attr_set) {
+                LSAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_mfma_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+                attr_set = true;
+            }
+            const float sc = 1.0f / sqrtf((float)a.hd);
+            hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(a.N * nwy * nwx, cdiv(a.nh, 4)), dim3(256), LDSB, s, a, sc,
+                               sc * 1.4426950408889634f);
+            LSAM_LAUNCH_CHECK();
+            return LSAM_OK;
+        }
+    }
     const int LDH = a.hd + 1, LDP = BW_NK + 1;
     const size_t lds = (size_t)(4 * BW_NK * LDH + 2 * BW_NK * LDP + 2 * BW_NK) * sizeof(float) + 2 * BW_NK * sizeof(int);
     auto kern = attn_bwd_kernel<T>;
     LSAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds));
-    const int nwy = cdiv(a.H, a.ws), nwx = cdiv(a.W, a.ws);
     hipLaunchKernelGGL(kern, dim3(a.N * nwy * nwx, a.nh), dim3(256), lds, s, a, 1.0f / sqrtf((float)a.hd));
     LSAM_LAUNCH_CHECK();
     return LSAM_OK;
