@@ -29,11 +29,13 @@ struct BlockGeom {
     int dim, dout, heads, ws, pool, gin, gout, stage;
     bool lora, need_dx;
     int kq;  // K of the qkv GEMM (dim or dim + AUG)
+    bool fused_attn;  // bf16 only: LN1 + qkv + window attention + proj + residual in one kernel (winblock.hip)
 };
 struct BlockOff {
     size_t ln1w, ln1b, wqkv, bqkv, wproj, bproj, ln2w, ln2b, w1, b1, w2, b2, wsc, bsc;
     size_t wqkvT, wprojT, w1T, w2T, acat, bT;
     size_t bqkvT;  // qkv bias in T (pad-token k/v source of the LDS-DMA attention kernel)
+    size_t wimg, wbias;  // fused window-block weight image + padded biases (winblock.hip), if g.fused_attn
 };
 
 }  // namespace lsam
@@ -202,6 +204,9 @@ static int pack_t(lsam_hiera* h, const lsam_block_params_t* bp, const float* pat
             LSAM_TRY(launch_pack_matrix<T>(p.proj_w, d, 1, q, d, at<T>(arena, o.wsc), d, s));
             LSAM_TRY(vec(p.proj_b, o.bsc, q));
         }
+        if (g.fused_attn)
+            LSAM_TRY(launch_pack_winblock(p.qkv_w, p.qkv_b, p.attn_proj_w, p.attn_proj_b, g.heads, q / g.heads,
+                                          at<char>(arena, o.wimg), at<float>(arena, o.wbias), s));
         if (g.lora) {  // transposed copies for dX = dY . W   (frozen: no dW GEMMs exist)
             LSAM_TRY(launch_pack_matrix<T>(p.fc2_w, 1, 4 * q, 4 * q, q, at<T>(arena, o.w2T), q, s));
             LSAM_TRY(launch_pack_matrix<T>(p.fc1_w, 1, q, q, 4 * q, at<T>(arena, o.w1T), 4 * q, s));
@@ -256,6 +261,14 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
         const bool grad = with_grad && g.lora;
         const int gi = (int)i - h->first_lora;
         const bool last = i + 1 == h->blk.size();
+        float* y;
+        if (g.fused_attn) {   // LN1 -> qkv -> window attention -> proj -> + x, in place, one kernel
+            WinBlockArgs wa{x, x, at<float>(arena, o.ln1w), at<float>(arena, o.ln1b), at<char>(arena, o.wimg),
+                            at<float>(arena, o.wbias), N, g.gin, g.gin, q / g.heads, 1e-6f,
+                            (1.0f / sqrtf((float)(q / g.heads))) * 1.4426950408889634f};
+            LSAM_TRY(launch_winblock_attn(wa, g.heads, s));
+            y = x;
+        } else {
         // ---- norm1 (+ LoRA u columns) -----------------------------------------------------------
         T* xn = grad ? at<T>(ws, w.sv[gi].xn) : at<T>(ws, w.xn);
         LSAM_TRY(launch_ln_fwd<T>(x, d, at<float>(arena, o.ln1w), at<float>(arena, o.ln1b), xn, g.kq,
@@ -264,7 +277,6 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
             LSAM_TRY(linear<T>(xn, g.kq, at<T>(arena, o.acat), d, nullptr, nullptr, 0, 0, nullptr, 0, xn + d, g.kq,
                                nullptr, 0, 0, Mi, AUG, d, s));
         // ---- residual target ----------------------------------------------------------------------
-        float* y;
         if (grad) y = at<float>(ws, w.sv[gi].y);
         else if (d != q) y = stage_out[g.stage];
         else y = x;
@@ -288,6 +300,7 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
         // ---- proj + residual  (hieradet.py:79,163) -------------------------------------------------
         LSAM_TRY(linear<T>(a, q, at<T>(arena, o.wproj), q, at<float>(arena, o.bproj), res, q, 0, nullptr, 0, y, q,
                            nullptr, 0, LSAM_EPI_OUT_F32, Mo, q, q, s));
+        }
         // ---- norm2 + MLP + residual  (hieradet.py:165) -----------------------------------------------
         T* yn = at<T>(ws, w.xn);
         LSAM_TRY(launch_ln_fwd<T>(y, q, at<float>(arena, o.ln2w), at<float>(arena, o.ln2b), yn, q,
@@ -426,6 +439,8 @@ int lsam_hiera_create(const lsam_hiera_config_t* c, lsam_hiera_t** out) {
         g.lora = c->n_lora_blocks > 0 && i >= depth - c->n_lora_blocks;
         g.need_dx = g.lora && i > depth - c->n_lora_blocks;
         g.kq = g.lora ? g.dim + AUG : g.dim;
+        g.fused_attn = c->dtype == LSAM_BF16 && !g.lora && g.dout % g.heads == 0 &&
+                       winblock_supported(g.gin, g.gin, g.ws, g.pool, g.heads, g.dout / g.heads, g.dim, g.dout);
         h->blk.push_back(g);
         dim = g.dout;
         grid = g.gout;
@@ -479,6 +494,10 @@ int lsam_hiera_create(const lsam_hiera_config_t* c, lsam_hiera_t** out) {
         if (d != q) {
             o.wsc = b.take(q * d * e);
             o.bsc = b.take(q * 4);
+        }
+        if (g.fused_attn) {
+            o.wimg = b.take(winblock_image_bytes(g.heads));
+            o.wbias = b.take(winblock_bias_floats(g.heads) * 4);
         }
         if (g.lora) {
             o.w2T = b.take(4 * q * q * e);

@@ -56,6 +56,23 @@ int launch_cast(const float* src, int lds, T* dst, int ldd, int rows, int cols, 
 template <typename T>
 int launch_im2col_patch(const float* img, T* cols, int ldc, int N, int S, hipStream_t s);
 
+// fused attention half of a same-dim 8x8-window block (winblock.hip)
+struct WinBlockArgs {
+    const float* x;       // [N*H*W][D] fp32 residual stream (D = nh * hd)
+    float* y;             // x + proj(attn(qkv(LN1(x)))); may alias x
+    const float* gamma; const float* beta;   // LayerNorm 1
+    const void* img;      // packed weight image (launch_pack_winblock)
+    const float* bias_p;  // padded qkv + proj biases
+    int N, H, W, hd;
+    float eps, c_log2;    // LN epsilon; softmax scale * log2(e)
+};
+size_t winblock_image_bytes(int nh);
+size_t winblock_bias_floats(int nh);
+bool winblock_supported(int H, int W, int ws, int pool, int nh, int hd, int dim, int dout);
+int launch_pack_winblock(const float* wqkv, const float* bqkv, const float* wproj, const float* bproj, int nh, int hd,
+                         void* img, float* bias_p, hipStream_t s);
+int launch_winblock_attn(const WinBlockArgs& a, int nh, hipStream_t s);
+
 size_t outer_reduce_ws(int M, int C);
 template <typename T>
 int launch_outer_reduce(const T* X, int ldx, const T* Y, int ldy, int M, int C, int R, float* out,
