@@ -30,12 +30,14 @@ struct BlockGeom {
     bool lora, need_dx;
     int kq;  // K of the qkv GEMM (dim or dim + AUG)
     bool fused_attn;  // bf16 only: LN1 + qkv + window attention + proj + residual in one kernel (winblock.hip)
+    bool fused_mlp;   // bf16 only: LN2 + fc1 + GELU + fc2 + residual in one kernel (mlpblock.hip)
 };
 struct BlockOff {
     size_t ln1w, ln1b, wqkv, bqkv, wproj, bproj, ln2w, ln2b, w1, b1, w2, b2, wsc, bsc;
     size_t wqkvT, wprojT, w1T, w2T, acat, bT;
     size_t bqkvT;  // qkv bias in T (pad-token k/v source of the LDS-DMA attention kernel)
     size_t wimg, wbias;  // fused window-block weight image + padded biases (winblock.hip), if g.fused_attn
+    size_t mimg, mbias;  // fused MLP weight image + fc2 bias (mlpblock.hip), if g.fused_mlp
 };
 
 }  // namespace lsam
@@ -207,6 +209,9 @@ static int pack_t(lsam_hiera* h, const lsam_block_params_t* bp, const float* pat
         if (g.fused_attn)
             LSAM_TRY(launch_pack_winblock(p.qkv_w, p.qkv_b, p.attn_proj_w, p.attn_proj_b, g.heads, q / g.heads,
                                           at<char>(arena, o.wimg), at<float>(arena, o.wbias), s));
+        if (g.fused_mlp)
+            LSAM_TRY(launch_pack_mlpblock(p.fc1_w, p.fc1_b, p.fc2_w, p.fc2_b, q, at<char>(arena, o.mimg),
+                                          at<float>(arena, o.mbias), s));
         if (g.lora) {  // transposed copies for dX = dY . W   (frozen: no dW GEMMs exist)
             LSAM_TRY(launch_pack_matrix<T>(p.fc2_w, 1, 4 * q, 4 * q, q, at<T>(arena, o.w2T), q, s));
             LSAM_TRY(launch_pack_matrix<T>(p.fc1_w, 1, q, q, 4 * q, at<T>(arena, o.w1T), 4 * q, s));
@@ -302,6 +307,12 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
                            nullptr, 0, LSAM_EPI_OUT_F32, Mo, q, q, s));
         }
         // ---- norm2 + MLP + residual  (hieradet.py:165) -----------------------------------------------
+        if (g.fused_mlp) {   // one kernel, in place on the residual stream
+            MlpBlockArgs ma{y, y, at<float>(arena, o.ln2w), at<float>(arena, o.ln2b), at<char>(arena, o.mimg),
+                            at<float>(arena, o.mbias), Mo, q, mlpblock_chunks(q), 1e-6f};
+            LSAM_TRY(launch_mlpblock(ma, s));
+            x = y;
+        } else {
         T* yn = at<T>(ws, w.xn);
         LSAM_TRY(launch_ln_fwd<T>(y, q, at<float>(arena, o.ln2w), at<float>(arena, o.ln2b), yn, q,
                                   grad ? at<float>(ws, w.sv[gi].st2) : nullptr, Mo, q, 1e-6f, s));
@@ -315,6 +326,7 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
         LSAM_TRY(linear<T>(hb, 4 * q, at<T>(arena, o.w2), 4 * q, at<float>(arena, o.b2), y, q, 0, nullptr, 0, out, q,
                            nullptr, 0, LSAM_EPI_OUT_F32, Mo, q, 4 * q, s));
         x = out;
+        }
         // a stage's last block must leave its result in the caller's stage buffer
         if ((last || h->blk[i + 1].stage != g.stage) && x != stage_out[g.stage]) {
             LSAM_HIP(hipMemcpyAsync(stage_out[g.stage], x, (size_t)Mo * q * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -441,6 +453,7 @@ int lsam_hiera_create(const lsam_hiera_config_t* c, lsam_hiera_t** out) {
         g.kq = g.lora ? g.dim + AUG : g.dim;
         g.fused_attn = c->dtype == LSAM_BF16 && !g.lora && g.dout % g.heads == 0 &&
                        winblock_supported(g.gin, g.gin, g.ws, g.pool, g.heads, g.dout / g.heads, g.dim, g.dout);
+        g.fused_mlp = c->dtype == LSAM_BF16 && !g.lora && mlpblock_supported(g.dout);
         h->blk.push_back(g);
         dim = g.dout;
         grid = g.gout;
@@ -498,6 +511,10 @@ int lsam_hiera_create(const lsam_hiera_config_t* c, lsam_hiera_t** out) {
         if (g.fused_attn) {
             o.wimg = b.take(winblock_image_bytes(g.heads));
             o.wbias = b.take(winblock_bias_floats(g.heads) * 4);
+        }
+        if (g.fused_mlp) {
+            o.mimg = b.take(mlpblock_image_bytes(g.dout));
+            o.mbias = b.take(mlpblock_bias_floats(g.dout) * 4);
         }
         if (g.lora) {
             o.w2T = b.take(4 * q * q * e);

@@ -73,6 +73,24 @@ int launch_pack_winblock(const float* wqkv, const float* bqkv, const float* wpro
                          void* img, float* bias_p, hipStream_t s);
 int launch_winblock_attn(const WinBlockArgs& a, int nh, hipStream_t s);
 
+// fused MLP half of a block: y = x + fc2(GELU(fc1(LN2(x))))  (mlpblock.hip)
+struct MlpBlockArgs {
+    const float* x;       // [M][d] fp32 residual stream
+    float* y;             // may alias x
+    const float* gamma; const float* beta;   // LayerNorm 2
+    const void* img;      // packed, chunked weight image (launch_pack_mlpblock)
+    const float* bias_p;  // fc1 bias padded to 64 * nch, then fc2 bias
+    int M, d, nch;
+    float eps;
+};
+bool mlpblock_supported(int d);
+int mlpblock_chunks(int d);
+size_t mlpblock_image_bytes(int d);
+size_t mlpblock_bias_floats(int d);
+int launch_pack_mlpblock(const float* w1, const float* b1, const float* w2, const float* b2, int d, void* img,
+                         float* bias_p, hipStream_t s);
+int launch_mlpblock(const MlpBlockArgs& a, hipStream_t s);
+
 size_t outer_reduce_ws(int M, int C);
 template <typename T>
 int launch_outer_reduce(const T* X, int ldx, const T* Y, int ldy, int M, int C, int R, float* out,

@@ -1,0 +1,304 @@
+// Fused MLP half of a MultiScaleBlock (hieradet.py:165, sam2_utils.py:112-136) for the narrow,
+// HBM-bound stages:   y = x + fc2(GELU(fc1(LN2(x))))   in ONE kernel: x is read once and y written
+// once; LN2's output, the 4d-wide hidden activation and its GELU never exist in HBM.
+//
+// A wave owns 16*MT consecutive tokens and keeps all of their activations in registers as MFMA
+// operands.  The hidden dimension is walked in chunks of 64:
+//   acc1 = W1[chunk] . xn^T            (swapped product: lane = token, 4 consecutive hidden units)
+//   h    = GELU(acc1 + b1)             -> bf16, which IS the B-operand layout of the next product once
+//                                         the K order of W2 is permuted to match (done when packing)
+//   acc2 += W2[:, chunk] . h^T         (lane = token, 4 consecutive output channels)
+// The weight chunks (W1 rows + W2 columns + the chunk's fc1 biases, 30-60 KiB) are packed once into the exact LDS image and
+// streamed global -> LDS by LDS-DMA, double-buffered: all waves of the workgroup walk the chunks in
+// lock-step (one barrier per chunk) and the DMA of chunk c+1 lands while chunk c is multiplied.
+#include "kernels.hpp"
+
+namespace lsam {
+
+typedef __attribute__((address_space(3))) void* mlp_lds_p;
+typedef const __attribute__((address_space(1))) void* mlp_gbl_p;
+
+template <int KS, int NTO> struct MlpImg {
+    static constexpr int NSUB = (KS + 1) / 2;                  // [64][64] sub-tiles of a W1 chunk
+    static constexpr int W1_B = NSUB * 64 * 128;
+    static constexpr int W2_B = NTO * 16 * 128;
+    static constexpr int B1_OFF = W1_B + W2_B;                 // the chunk's 64 fc1 biases (fp32), padded to 1 KiB
+    static constexpr int CHUNK_B = W1_B + W2_B + 1024;         // multiple of 1024
+};
+
+__host__ __device__ inline int mlp_slot_to_ch(int s) {
+    const int ks = s >> 5, g = (s >> 3) & 3, t = (s >> 2) & 1, r = s & 3;
+    return 32 * ks + 16 * t + 4 * g + r;
+}
+
+template <int KS, int NTO>
+__global__ void pack_mlpblock_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
+                                     const float* __restrict__ w2, const float* __restrict__ b2, int d, int nch,
+                                     char* __restrict__ img, float* __restrict__ bias_p) {
+    using I = MlpImg<KS, NTO>;
+    const int hid = 4 * d;
+    const long total = (long)nch * I::CHUNK_B / 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long byte = 2 * i;
+        const int c = (int)(byte / I::CHUNK_B), in = (int)(byte % I::CHUNK_B);
+        float v = 0.f;
+        if (in >= I::B1_OFF) {   // fp32 biases are written by the loop below
+            continue;
+        } else if (in < I::W1_B) {
+            const int kk = in / 8192, r8 = in % 8192;
+            const int row = r8 / 128, chunk = ((r8 % 128) >> 4) ^ (row & 7), k = 64 * kk + 8 * chunk + ((r8 & 15) >> 1);
+            const int hrow = c * 64 + row;
+            if (hrow < hid && k < d) v = w1[(size_t)hrow * d + k];
+        } else {
+            const int r8 = in - I::W1_B;
+            const int row = r8 / 128, chunk = ((r8 % 128) >> 4) ^ (row & 7), slot = 8 * chunk + ((r8 & 15) >> 1);
+            const int hcol = c * 64 + mlp_slot_to_ch(slot);
+            if (row < d && hcol < hid) v = w2[(size_t)row * hid + hcol];
+        }
+        reinterpret_cast<bf16*>(img)[i] = (bf16)v;
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nch * 256; i += gridDim.x * blockDim.x) {
+        const int c = i / 256, e = i % 256;   // 256 floats = the chunk's 1 KiB bias slot
+        reinterpret_cast<float*>(img + (size_t)c * I::CHUNK_B + I::B1_OFF)[e] = (e < 64 && c * 64 + e < hid) ? b1[c * 64 + e] : 0.f;
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < NTO * 16; i += gridDim.x * blockDim.x)
+        bias_p[i] = i < d ? b2[i] : 0.f;
+}
+
+template <int KS, int NTO, int MT, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void mlpblock_kernel(const MlpBlockArgs p) {
+    using I = MlpImg<KS, NTO>;
+    constexpr int CB = I::CHUNK_B, TPW = 16 * MT, TPG = TPW * NW;
+    constexpr int NDMA = CB / 1024;   // 1 KiB DMA wave-instructions per chunk
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, lr = lane & 15;
+    const int d = p.d, M = p.M, nch = p.nch;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ b2p = p.bias_p;
+    const char* __restrict__ img = static_cast<const char*>(p.img);
+
+    auto issue = [&](int c, int buf) {
+        const char* src = img + (size_t)c * CB;
+        char* dst = smem + buf * CB;
+#pragma unroll
+        for (int i = 0; i < (NDMA + NW - 1) / NW; ++i) {
+            const int j = wave + NW * i;
+            if (j < NDMA)
+                __builtin_amdgcn_global_load_lds((mlp_gbl_p)(src + j * 1024 + lane * 16), (mlp_lds_p)(dst + j * 1024), 16, 0, 0);
+        }
+    };
+    auto wfrag = [&](const char* base, int row, int c) -> bf16x8 {
+        return *reinterpret_cast<const bf16x8*>(base + row * 128 + ((c ^ (row & 7)) << 4));
+    };
+
+    const int ngroups = (M + TPG - 1) / TPG;
+    int buf = 0;
+    issue(0, 0);
+#pragma unroll 1
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int m0 = grp * TPG + wave * TPW;
+        // ---- LayerNorm 2 into operand fragments (rows past M are clamped and never stored) -----------
+        bf16x8 xn[MT][KS];
+        {
+            float xr[MT][KS][8], sum[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = min(m0 + mt * 16 + lr, M - 1);
+                const float* row = p.x + (size_t)m * d;
+                sum[mt] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int c0 = 32 * ks + 8 * g;
+                    f32x4 a = zero4, b = zero4;
+                    if (c0 < d) { a = load4(row + c0); b = load4(row + c0 + 4); }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { xr[mt][ks][j] = a[j]; xr[mt][ks][4 + j] = b[j]; }
+                    sum[mt] += ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]));
+                }
+            }
+            float mean[MT], rstd[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float s = sum[mt];
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                mean[mt] = s / (float)d;
+                float q = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    if (32 * ks + 8 * g < d) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float dd = xr[mt][ks][j] - mean[mt];
+                            q += dd * dd;
+                        }
+                    }
+                q += __shfl_xor(q, 16, 64);
+                q += __shfl_xor(q, 32, 64);
+                rstd[mt] = 1.0f / sqrtf(q / (float)d + p.eps);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int c0 = 32 * ks + 8 * g;
+                const bool ok = c0 < d;
+                f32x4 g0 = zero4, g1 = zero4, b0 = zero4, b1 = zero4;
+                if (ok) {
+                    g0 = load4(p.gamma + c0); g1 = load4(p.gamma + c0 + 4);
+                    b0 = load4(p.beta + c0);  b1 = load4(p.beta + c0 + 4);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    bf16x8 f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f[j] = (bf16)(ok ? (xr[mt][ks][j] - mean[mt]) * rstd[mt] * g0[j] + b0[j] : 0.f);
+                        f[4 + j] = (bf16)(ok ? (xr[mt][ks][4 + j] - mean[mt]) * rstd[mt] * g1[j] + b1[j] : 0.f);
+                    }
+                    xn[mt][ks] = f;
+                }
+            }
+        }
+        f32x4 acc2[MT][NTO];
+#pragma unroll
+        for (int nt = 0; nt < NTO; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc2[mt][nt] = zero4;
+
+#pragma unroll 1
+        for (int c = 0; c < nch; ++c) {
+            lds_dma_wait_barrier();   // chunk c landed; every wave is done with the other buffer
+            {
+                // next chunk in stream order (wraps to chunk 0 of the next token group)
+                const bool more = c + 1 < nch || grp + (int)gridDim.x < ngroups;
+                if (more) issue(c + 1 < nch ? c + 1 : 0, buf ^ 1);
+            }
+            const char* w1b = smem + buf * CB;
+            const char* w2b = w1b + I::W1_B;
+            f32x4 acc1[MT][4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(w1b + I::B1_OFF + (16 * nt + 4 * g) * 4);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc1[mt][nt] = b;
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const bf16x8 wf = wfrag(w1b + (ks >> 1) * 8192, 16 * nt + lr, (ks & 1) * 4 + g);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) mma16(wf, xn[mt][ks], acc1[mt][nt]);
+                }
+            __builtin_amdgcn_sched_barrier(0);   // keep the W2 fragment reads from being hoisted above the GELU
+            bf16x8 hf[MT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    bf16x8 f;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) f[4 * t + r] = (bf16)gelu_t<true>(acc1[mt][2 * k2 + t][r]);
+                    hf[mt][k2] = f;
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt) {
+                    const bf16x8 wf = wfrag(w2b, 16 * nt + lr, k2 * 4 + g);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) mma16(wf, hf[mt][k2], acc2[mt][nt]);
+                }
+            buf ^= 1;
+        }
+        // ---- fc2 bias + residual + store: one row block's operands are requested together -------------
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + mt * 16 + lr;
+            const float* xrow = p.x + (size_t)min(m, M - 1) * d;
+            f32x4 r[NTO];
+#pragma unroll
+            for (int nt = 0; nt < NTO; ++nt) {
+                const int c0 = min(16 * nt + 4 * g, d - 4);
+                r[nt] = load4(xrow + c0) + load4(b2p + c0);
+            }
+            if (m < M) {
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt) {
+                    const int c0 = 16 * nt + 4 * g;
+                    if (c0 < d) store4(p.y + (size_t)m * d + c0, acc2[mt][nt] + r[nt]);
+                }
+            }
+        }
+    }
+}
+
+// supported widths: d <= 64 (KS 2), d <= 128 (KS 4), d <= 224 (KS 7); d % 8 == 0
+static int mlp_variant(int d) {
+    if (d % 8 != 0 || d < 16) return -1;
+    if (d <= 64) return 0;
+    if (d <= 112) return 1;
+    if (d > 128 && d <= 224) return 2;
+    return -1;
+}
+bool mlpblock_supported(int d) { return mlp_variant(d) >= 0; }
+int mlpblock_chunks(int d) { return (4 * d + 63) / 64; }
+size_t mlpblock_image_bytes(int d) {
+    const int nch = mlpblock_chunks(d);
+    switch (mlp_variant(d)) {
+        case 0: return (size_t)nch * MlpImg<2, 4>::CHUNK_B;
+        case 1: return (size_t)nch * MlpImg<4, 7>::CHUNK_B;
+        case 2: return (size_t)nch * MlpImg<7, 14>::CHUNK_B;
+    }
+    return 0;
+}
+size_t mlpblock_bias_floats(int) { return 16 * 14; }
+
+int launch_pack_mlpblock(const float* w1, const float* b1, const float* w2, const float* b2, int d, void* img,
+                         float* bias_p, hipStream_t s) {
+    LSAM_REQUIRE(w1 && b1 && w2 && b2 && img && bias_p, LSAM_ERR_BAD_ARG, "pack_mlpblock: null argument");
+    const int v = mlp_variant(d), nch = mlpblock_chunks(d);
+    LSAM_REQUIRE(v >= 0, LSAM_ERR_UNSUPPORTED, "pack_mlpblock: width %d", d);
+    char* im = static_cast<char*>(img);
+    if (v == 0) hipLaunchKernelGGL((pack_mlpblock_kernel<2, 4>), dim3(128), dim3(256), 0, s, w1, b1, w2, b2, d, nch, im, bias_p);
+    if (v == 1) hipLaunchKernelGGL((pack_mlpblock_kernel<4, 7>), dim3(128), dim3(256), 0, s, w1, b1, w2, b2, d, nch, im, bias_p);
+    if (v == 2) hipLaunchKernelGGL((pack_mlpblock_kernel<7, 14>), dim3(128), dim3(256), 0, s, w1, b1, w2, b2, d, nch, im, bias_p);
+    LSAM_LAUNCH_CHECK();
+    return LSAM_OK;
+}
+
+template <int KS, int NTO, int MT, int NW> static int launch_mlp(const MlpBlockArgs& a, hipStream_t s) {
+    constexpr int LDSB = 2 * MlpImg<KS, NTO>::CHUNK_B;
+    auto kern = mlpblock_kernel<KS, NTO, MT, NW>;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        LSAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+        attr_set = true;
+    }
+    const int ngroups = cdiv(a.M, 16 * MT * NW);
+    const int grid = ngroups < 256 ? ngroups : 256;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), LDSB, s, a);
+    LSAM_LAUNCH_CHECK();
+    return LSAM_OK;
+}
+
+int launch_mlpblock(const MlpBlockArgs& a, hipStream_t s) {
+    LSAM_REQUIRE(a.x && a.y && a.gamma && a.beta && a.img && a.bias_p, LSAM_ERR_BAD_ARG, "mlpblock: null argument");
+    LSAM_REQUIRE(a.M > 0 && a.nch == mlpblock_chunks(a.d), LSAM_ERR_BAD_ARG, "mlpblock: bad shape");
+    LSAM_REQUIRE(aligned16(a.x) && aligned16(a.y) && aligned16(a.img) && aligned16(a.gamma) && aligned16(a.beta) &&
+                     aligned16(a.bias_p), LSAM_ERR_BAD_ARG, "mlpblock: pointers must be 16-byte aligned");
+    switch (mlp_variant(a.d)) {
+        case 0: return launch_mlp<2, 4, 2, 8>(a, s);
+        case 1: return launch_mlp<4, 7, 2, 8>(a, s);
+        case 2: return launch_mlp<7, 14, 2, 8>(a, s);
+    }
+    set_error("mlpblock: width %d not supported", a.d);
+    return LSAM_ERR_UNSUPPORTED;
+}
+
+}  // namespace lsam
