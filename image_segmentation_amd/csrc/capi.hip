@@ -92,6 +92,34 @@ int lsam_im2col_patch(int dtype, const float* img, void* cols, int ldc, int N, i
              launch_im2col_patch<bf16>(img, static_cast<bf16*>(cols), ldc, N, S, s));
 }
 
+size_t lsam_window_block_image_bytes(int nh) { return (nh == 1 || nh == 2) ? winblock_image_bytes(nh) : 0; }
+size_t lsam_window_block_bias_floats(int nh) { return (nh == 1 || nh == 2) ? winblock_bias_floats(nh) : 0; }
+int lsam_window_block_pack(const float* qkv_w, const float* qkv_b, const float* proj_w, const float* proj_b, int nh,
+                           int hd, void* image, float* bias_table, lsam_stream_t stream) {
+    return launch_pack_winblock(qkv_w, qkv_b, proj_w, proj_b, nh, hd, image, bias_table, static_cast<hipStream_t>(stream));
+}
+int lsam_window_block_fwd(const float* x, float* y, const float* norm1_w, const float* norm1_b, const void* image,
+                          const float* bias_table, int N, int H, int W, int nh, int hd, float eps,
+                          lsam_stream_t stream) {
+    LSAM_REQUIRE(hd > 0, LSAM_ERR_BAD_ARG, "window_block: head_dim must be positive");
+    const WinBlockArgs a{x, y, norm1_w, norm1_b, image, bias_table, N, H, W, hd, eps,
+                         (1.0f / sqrtf((float)hd)) * 1.4426950408889634f};
+    return launch_winblock_attn(a, nh, static_cast<hipStream_t>(stream));
+}
+
+size_t lsam_mlp_block_image_bytes(int d) { return mlpblock_supported(d) ? mlpblock_image_bytes(d) : 0; }
+size_t lsam_mlp_block_bias_floats(int d) { return mlpblock_supported(d) ? mlpblock_bias_floats(d) : 0; }
+int lsam_mlp_block_pack(const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b, int d,
+                        void* image, float* bias_table, lsam_stream_t stream) {
+    return launch_pack_mlpblock(fc1_w, fc1_b, fc2_w, fc2_b, d, image, bias_table, static_cast<hipStream_t>(stream));
+}
+int lsam_mlp_block_fwd(const float* x, float* y, const float* norm2_w, const float* norm2_b, const void* image,
+                       const float* bias_table, int M, int d, float eps, lsam_stream_t stream) {
+    LSAM_REQUIRE(mlpblock_supported(d), LSAM_ERR_UNSUPPORTED, "mlp_block: width %d not supported", d);
+    const MlpBlockArgs a{x, y, norm2_w, norm2_b, image, bias_table, M, d, mlpblock_chunks(d), eps};
+    return launch_mlpblock(a, static_cast<hipStream_t>(stream));
+}
+
 int lsam_prof_arm(int capacity) { return prof_arm(capacity); }
 int lsam_prof_read(int max, float* host_ms, double* host_flops, int* host_cfg, int* host_mnk) {
     LSAM_REQUIRE(host_ms && host_flops && host_cfg && max >= 0, LSAM_ERR_BAD_ARG, "prof_read: null argument");

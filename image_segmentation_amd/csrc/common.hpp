@@ -127,9 +127,24 @@ __device__ __forceinline__ float erf_fast(float x) {
     y = y * t * __expf(-ax * ax);
     return copysignf(1.0f - y, x);
 }
+// bf16 forward GELU: x * Phi(x) with Phi(x) = sigmoid(x * P(x^2)), P a cubic in x^2 fitted (minimax,
+// error measured relative to max(|gelu|, 0.02)) to the exact erf form on |x| <= 7:
+// |abs err| <= 4.1e-5 everywhere and relative error <= 0.15 % wherever |gelu(x)| > 1e-3, i.e. below
+// the 0.2-0.4 % half-ulp of the bf16 value it is rounded to.  10 VALU ops (2 transcendental) against
+// ~17 for the erf form: the GELU is what bounds the fused MLP kernel and the fc1 epilogue.
+// The coefficients carry the factor -log2(e) so that the sigmoid is 1 / (1 + exp2(x * P)).
+__device__ __forceinline__ float gelu_sig(float x) {
+    const float xc = __builtin_amdgcn_fmed3f(x, -7.0f, 7.0f);
+    const float x2 = xc * xc;
+    float p = fmaf(1.0147823e-05f, x2, 9.6327340e-04f);   // -log2e * (-7.033935387e-06, -6.676902593e-04)
+    p = fmaf(p, x2, -1.0691202e-01f);                     // -log2e * 7.410576139e-02
+    p = fmaf(p, x2, -2.3007577e+00f);                     // -log2e * 1.594763726
+    const float e = __builtin_amdgcn_exp2f(xc * p);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
 template <bool FAST> __device__ __forceinline__ float gelu_t(float x) {
-    const float e = FAST ? erf_fast(x * 0.70710678118654752f) : erff(x * 0.70710678118654752f);
-    return 0.5f * x * (1.0f + e);
+    if constexpr (FAST) return gelu_sig(x);
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
 }
 template <bool FAST> __device__ __forceinline__ float gelu_grad_t(float x) {
     const float e = FAST ? erf_fast(x * 0.70710678118654752f) : erff(x * 0.70710678118654752f);

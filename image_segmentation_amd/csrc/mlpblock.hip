@@ -15,6 +15,9 @@
 
 namespace lsam {
 
+#ifndef MLP_ABL
+#define MLP_ABL 0
+#endif
 typedef __attribute__((address_space(3))) void* mlp_lds_p;
 typedef const __attribute__((address_space(1))) void* mlp_gbl_p;
 
@@ -66,7 +69,7 @@ __global__ void pack_mlpblock_kernel(const float* __restrict__ w1, const float* 
 }
 
 template <int KS, int NTO, int MT, int NW>
-__global__ __launch_bounds__(64 * NW, 1) void mlpblock_kernel(const MlpBlockArgs p) {
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlpblock_kernel(const MlpBlockArgs p) {
     using I = MlpImg<KS, NTO>;
     constexpr int CB = I::CHUNK_B, TPW = 16 * MT, TPG = TPW * NW;
     constexpr int NDMA = CB / 1024;   // 1 KiB DMA wave-instructions per chunk
@@ -81,6 +84,9 @@ __global__ __launch_bounds__(64 * NW, 1) void mlpblock_kernel(const MlpBlockArgs
     const char* __restrict__ img = static_cast<const char*>(p.img);
 
     auto issue = [&](int c, int buf) {
+#if MLP_ABL & 1
+        return;
+#endif
         const char* src = img + (size_t)c * CB;
         char* dst = smem + buf * CB;
 #pragma unroll
@@ -175,6 +181,10 @@ __global__ __launch_bounds__(64 * NW, 1) void mlpblock_kernel(const MlpBlockArgs
                 const bool more = c + 1 < nch || grp + (int)gridDim.x < ngroups;
                 if (more) issue(c + 1 < nch ? c + 1 : 0, buf ^ 1);
             }
+#if MLP_ABL & 2
+            buf ^= 1;
+            continue;
+#endif
             const char* w1b = smem + buf * CB;
             const char* w2b = w1b + I::W1_B;
             f32x4 acc1[MT][4];
@@ -202,7 +212,12 @@ __global__ __launch_bounds__(64 * NW, 1) void mlpblock_kernel(const MlpBlockArgs
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) f[4 * t + r] = (bf16)gelu_t<true>(acc1[mt][2 * k2 + t][r]);
+                        for (int r = 0; r < 4; ++r)
+#if MLP_ABL & 4
+                            f[4 * t + r] = (bf16)(acc1[mt][2 * k2 + t][r]);
+#else
+                            f[4 * t + r] = (bf16)gelu_t<true>(acc1[mt][2 * k2 + t][r]);
+#endif
                     hf[mt][k2] = f;
                 }
             __builtin_amdgcn_sched_barrier(0);
@@ -281,7 +296,10 @@ template <int KS, int NTO, int MT, int NW> static int launch_mlp(const MlpBlockA
         attr_set = true;
     }
     const int ngroups = cdiv(a.M, 16 * MT * NW);
-    const int grid = ngroups < 256 ? ngroups : 256;
+    // persistent; two 4-wave workgroups share a CU when their LDS fits, so that one workgroup's
+    // memory phases (LayerNorm reads, residual + store) overlap the other's MFMA/GELU phases
+    const int per_cu = (NW == 4 && 2 * LDSB <= 160 * 1024) ? 2 : 1;
+    const int grid = ngroups < 256 * per_cu ? ngroups : 256 * per_cu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), LDSB, s, a);
     LSAM_LAUNCH_CHECK();
     return LSAM_OK;
@@ -293,8 +311,8 @@ int launch_mlpblock(const MlpBlockArgs& a, hipStream_t s) {
     LSAM_REQUIRE(aligned16(a.x) && aligned16(a.y) && aligned16(a.img) && aligned16(a.gamma) && aligned16(a.beta) &&
                      aligned16(a.bias_p), LSAM_ERR_BAD_ARG, "mlpblock: pointers must be 16-byte aligned");
     switch (mlp_variant(a.d)) {
-        case 0: return launch_mlp<2, 4, 2, 8>(a, s);
-        case 1: return launch_mlp<4, 7, 2, 8>(a, s);
+        case 0: return launch_mlp<2, 4, 2, 4>(a, s);
+        case 1: return launch_mlp<4, 7, 2, 4>(a, s);
         case 2: return launch_mlp<7, 14, 2, 8>(a, s);
     }
     set_error("mlpblock: width %d not supported", a.d);

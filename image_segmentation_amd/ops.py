@@ -161,3 +161,53 @@ def outer_reduce(X: torch.Tensor, Y: torch.Tensor, R: int, transpose_out: bool) 
     check(lib().lsam_outer_reduce(dtype_code(X.dtype), ptr(X), ldx, ptr(Y), ldy, M, Cc, R, ptr(out), cs, ks,
                                   ptr(ws), stream()))
     return out
+
+
+def window_block_pack(qkv_w, qkv_b, proj_w, proj_b, nh: int):
+    """fp32 module parameters -> (weight image uint8, bias table fp32) of the fused window-block kernel."""
+    _need_gpu(qkv_w, qkv_b, proj_w, proj_b)
+    d = proj_w.shape[0]
+    hd = d // nh
+    nbytes, nfl = lib().lsam_window_block_image_bytes(nh), lib().lsam_window_block_bias_floats(nh)
+    if nbytes == 0:
+        raise _C.LsamError(f"fused window block: {nh} heads not supported")
+    img = torch.empty(nbytes, dtype=torch.uint8, device=qkv_w.device)
+    bias = torch.empty(nfl, dtype=torch.float32, device=qkv_w.device)
+    args = [t.detach().float().contiguous() for t in (qkv_w, qkv_b, proj_w, proj_b)]
+    check(lib().lsam_window_block_pack(*[ptr(t) for t in args], nh, hd, ptr(img), ptr(bias), stream()))
+    return img, bias
+
+
+def window_block_fwd(x, norm1_w, norm1_b, img, bias, nh: int, eps: float = 1e-6, out=None):
+    """y = x + proj(attn(qkv(LN1(x)))) for x fp32 [N,H,W,d] with 8x8 windows (see lsam_window_block_fwd)."""
+    _need_gpu(x, norm1_w, norm1_b, img, bias)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    N, H, W, d = x.shape
+    y = torch.empty_like(x) if out is None else out
+    check(lib().lsam_window_block_fwd(ptr(x), ptr(y), ptr(norm1_w), ptr(norm1_b), ptr(img), ptr(bias), N, H, W, nh,
+                                      d // nh, eps, stream()))
+    return y
+
+
+def mlp_block_pack(fc1_w, fc1_b, fc2_w, fc2_b):
+    _need_gpu(fc1_w, fc1_b, fc2_w, fc2_b)
+    d = fc2_w.shape[0]
+    nbytes, nfl = lib().lsam_mlp_block_image_bytes(d), lib().lsam_mlp_block_bias_floats(d)
+    if nbytes == 0:
+        raise _C.LsamError(f"fused MLP block: width {d} not supported")
+    img = torch.empty(nbytes, dtype=torch.uint8, device=fc1_w.device)
+    bias = torch.empty(nfl, dtype=torch.float32, device=fc1_w.device)
+    args = [t.detach().float().contiguous() for t in (fc1_w, fc1_b, fc2_w, fc2_b)]
+    check(lib().lsam_mlp_block_pack(*[ptr(t) for t in args], d, ptr(img), ptr(bias), stream()))
+    return img, bias
+
+
+def mlp_block_fwd(x, norm2_w, norm2_b, img, bias, eps: float = 1e-6, out=None):
+    """y = x + fc2(GELU(fc1(LN2(x)))) for x fp32 [M, d] (see lsam_mlp_block_fwd)."""
+    _need_gpu(x, norm2_w, norm2_b, img, bias)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+    M, d = x.shape
+    y = torch.empty_like(x) if out is None else out
+    check(lib().lsam_mlp_block_fwd(ptr(x), ptr(y), ptr(norm2_w), ptr(norm2_b), ptr(img), ptr(bias), M, d, eps,
+                                   stream()))
+    return y

@@ -132,6 +132,35 @@ size_t lsam_outer_reduce_ws(int M, int C);
 int lsam_outer_reduce(int dtype, const void* X, int ldx, const void* Y, int ldy, int M, int C, int R,
                       float* out, long out_cs, long out_ks, void* partial, lsam_stream_t stream);
 
+/* Fused attention half of a same-width 8x8-window block, bf16 MFMA, in one kernel:
+ *   y = x + proj(attn(qkv(LayerNorm1(x))))       (MultiScaleBlock.forward, hieradet.py:134-163 with
+ *   window_partition/unpartition, backbones/utils.py:16-60, and MultiScaleAttention.forward,
+ *   hieradet.py:56-81, for dim == dim_out, window 8, no q-pool, grid a multiple of 8: the stage-1 blocks).
+ * x, y fp32 [N*H*W][nh*hd] token-major NHWC (y may alias x); nh in {1, 2}; hd <= 64, hd % 8 == 0.
+ * lsam_window_block_pack builds the weight image (lsam_window_block_image_bytes bytes) and the
+ * padded bias table (lsam_window_block_bias_floats floats) from the fp32 module parameters
+ * (attn.qkv.weight [3d][d], attn.qkv.bias, attn.proj.weight [d][d], attn.proj.bias). */
+size_t lsam_window_block_image_bytes(int nh);
+size_t lsam_window_block_bias_floats(int nh);
+int lsam_window_block_pack(const float* qkv_w, const float* qkv_b, const float* proj_w, const float* proj_b,
+                           int nh, int hd, void* image, float* bias_table, lsam_stream_t stream);
+int lsam_window_block_fwd(const float* x, float* y, const float* norm1_w, const float* norm1_b,
+                          const void* image, const float* bias_table, int N, int H, int W, int nh, int hd,
+                          float eps, lsam_stream_t stream);
+
+/* Fused MLP half of a block, bf16 MFMA, in one kernel:
+ *   y = x + fc2(GELU(fc1(LayerNorm2(x))))         (hieradet.py:165, MLP: sam2_utils.py:112-136)
+ * x, y fp32 [M][d] (y may alias x); d % 8 == 0 and d <= 112 or 128 < d <= 224 (the stage-1/2 widths).
+ * lsam_mlp_block_pack builds the chunked weight image (lsam_mlp_block_image_bytes(d) bytes) and the
+ * fc2 bias table (lsam_mlp_block_bias_floats(d) floats) from mlp.layers.0.{weight [4d][d], bias} and
+ * mlp.layers.1.{weight [d][4d], bias}. */
+size_t lsam_mlp_block_image_bytes(int d);
+size_t lsam_mlp_block_bias_floats(int d);
+int lsam_mlp_block_pack(const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b, int d,
+                        void* image, float* bias_table, lsam_stream_t stream);
+int lsam_mlp_block_fwd(const float* x, float* y, const float* norm2_w, const float* norm2_b, const void* image,
+                       const float* bias_table, int M, int d, float eps, lsam_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Whole-trunk plan: Hiera.forward / Hiera.get_embedding (hieradet.py:284-334) with
  * LoRA_qkv on the last blocks (lora_qkv.py:102-109,162) and the autograd graph that

@@ -192,3 +192,68 @@ def test_outer_reduce(ops, dt):
     assert rel_err(gt, ref.t()) < 1e-5
     g2 = ops.outer_reduce(X[:, :C], Y[:, 16:32], R, transpose_out=False)
     assert torch.equal(g, g2)   # deterministic two-pass reduction
+
+
+def _win_block_ref(x, g1, b1, wqkv, bqkv, wproj, bproj, nh):
+    """fp32 torch restatement of the attention half of MultiScaleBlock.forward (hieradet.py:134-163)
+    for a same-width block with 8x8 windows and no padding."""
+    N, H, W, d = x.shape
+    xn = F.layer_norm(x, (d,), g1, b1, 1e-6)
+    xw = xn.view(N, H // 8, 8, W // 8, 8, d).permute(0, 1, 3, 2, 4, 5).reshape(-1, 64, d)
+    qkv = (xw @ wqkv.t() + bqkv).reshape(-1, 64, 3, nh, d // nh)
+    q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
+    o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(-1, 64, d)
+    o = o @ wproj.t() + bproj
+    o = o.view(N, H // 8, W // 8, 8, 8, d).permute(0, 1, 3, 2, 4, 5).reshape(N, H, W, d)
+    return x + o
+
+
+@pytest.mark.parametrize("nh,hd,N,H", [(2, 56, 2, 32), (1, 56, 3, 16), (2, 64, 1, 24), (1, 32, 2, 8)])
+def test_fused_window_block(ops, nh, hd, N, H):
+    d = nh * hd
+    x = rnd(N, H, H, d, seed=1)
+    g1, b1 = 1 + 0.1 * rnd(d, seed=2), 0.1 * rnd(d, seed=3)
+    wqkv, bqkv = rnd(3 * d, d, seed=4) / math.sqrt(d), 0.2 * rnd(3 * d, seed=5)
+    wproj, bproj = rnd(d, d, seed=6) / math.sqrt(d), 0.2 * rnd(d, seed=7)
+    ref = _win_block_ref(x, g1, b1, wqkv, bqkv, wproj, bproj, nh)
+    dev = [t.cuda() for t in (wqkv, bqkv, wproj, bproj)]
+    img, bias = ops.window_block_pack(*dev, nh)
+    xg = x.cuda()
+    y = ops.window_block_fwd(xg, g1.cuda(), b1.cuda(), img, bias, nh)
+    # the residual x is carried in fp32: compare the bf16-computed update, not x + update
+    assert rel_err(y.cpu() - x, ref - x) < 1e-2
+    y2 = ops.window_block_fwd(xg, g1.cuda(), b1.cuda(), img, bias, nh, out=xg)   # in place
+    assert torch.equal(y2, y)
+
+
+def test_fused_window_block_rejects_unsupported(ops):
+    from image_segmentation_amd._C import LsamError
+    d = 112
+    w = [rnd(3 * d, d).cuda(), rnd(3 * d).cuda(), rnd(d, d).cuda(), rnd(d).cuda()]
+    img, bias = ops.window_block_pack(*w, 2)
+    x = rnd(1, 12, 12, d).cuda()   # 12 is not a multiple of the 8x8 window
+    with pytest.raises(LsamError):
+        ops.window_block_fwd(x, rnd(d).cuda(), rnd(d).cuda(), img, bias, 2)
+    with pytest.raises(LsamError):
+        ops.window_block_pack(rnd(12 * d, 4 * d).cuda(), rnd(12 * d).cuda(), rnd(4 * d, 4 * d).cuda(), rnd(4 * d).cuda(), 8)
+
+
+@pytest.mark.parametrize("d,M", [(112, 1000), (56, 300), (224, 777), (64, 256), (160, 100)])
+def test_fused_mlp_block(ops, d, M):
+    x = rnd(M, d, seed=11)
+    g2, b2 = 1 + 0.1 * rnd(d, seed=12), 0.1 * rnd(d, seed=13)
+    w1, c1 = rnd(4 * d, d, seed=14) / math.sqrt(d), 0.2 * rnd(4 * d, seed=15)
+    w2, c2 = rnd(d, 4 * d, seed=16) / math.sqrt(4 * d), 0.2 * rnd(d, seed=17)
+    ref = x + F.gelu(F.layer_norm(x, (d,), g2, b2, 1e-6) @ w1.t() + c1) @ w2.t() + c2
+    img, bias = ops.mlp_block_pack(w1.cuda(), c1.cuda(), w2.cuda(), c2.cuda())
+    xg = x.cuda()
+    y = ops.mlp_block_fwd(xg, g2.cuda(), b2.cuda(), img, bias)
+    assert rel_err(y.cpu() - x, ref - x) < 1e-2
+    y2 = ops.mlp_block_fwd(xg, g2.cuda(), b2.cuda(), img, bias, out=xg)   # in place
+    assert torch.equal(y2, y)
+
+
+def test_fused_mlp_block_rejects_unsupported(ops):
+    from image_segmentation_amd._C import LsamError
+    with pytest.raises(LsamError):
+        ops.mlp_block_pack(rnd(1792, 448).cuda(), rnd(1792).cuda(), rnd(448, 1792).cuda(), rnd(448).cuda())
