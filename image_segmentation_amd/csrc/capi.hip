@@ -120,6 +120,23 @@ int lsam_mlp_block_fwd(const float* x, float* y, const float* norm2_w, const flo
     return launch_mlpblock(a, static_cast<hipStream_t>(stream));
 }
 
+size_t lsam_tail_block_image_bytes(int d) { return tailblock_supported(d) ? tailblock_image_bytes(d) : 0; }
+size_t lsam_tail_block_vec_floats(int d) { return tailblock_supported(d) ? tailblock_vec_floats(d) : 0; }
+int lsam_tail_block_pack(const float* proj_w, const float* proj_b, const float* norm2_w, const float* norm2_b,
+                         const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b, int d,
+                         void* image, float* vec, lsam_stream_t stream) {
+    return launch_pack_tailblock(proj_w, proj_b, norm2_w, norm2_b, fc1_w, fc1_b, fc2_w, fc2_b, d, image, vec,
+                                 static_cast<hipStream_t>(stream));
+}
+int lsam_tail_block_fwd(const void* a, int lda, const float* res, float* out, const void* image, const float* vec,
+                        void* xn_next, int ldn, const float* next_norm_w, const float* next_norm_b, int M, int d,
+                        float eps, lsam_stream_t stream) {
+    LSAM_REQUIRE(tailblock_supported(d), LSAM_ERR_UNSUPPORTED, "tail_block: width %d not supported", d);
+    const TailBlockArgs t{a, lda, res, out, image, vec, xn_next, ldn, next_norm_w, next_norm_b, M, d,
+                          tailblock_chunks(d), eps};
+    return launch_tailblock(t, static_cast<hipStream_t>(stream));
+}
+
 int lsam_prof_arm(int capacity) { return prof_arm(capacity); }
 int lsam_prof_read(int max, float* host_ms, double* host_flops, int* host_cfg, int* host_mnk) {
     LSAM_REQUIRE(host_ms && host_flops && host_cfg && max >= 0, LSAM_ERR_BAD_ARG, "prof_read: null argument");

@@ -31,6 +31,7 @@ struct BlockGeom {
     int kq;  // K of the qkv GEMM (dim or dim + AUG)
     bool fused_attn;  // bf16 only: LN1 + qkv + window attention + proj + residual in one kernel (winblock.hip)
     bool fused_mlp;   // bf16 only: LN2 + fc1 + GELU + fc2 + residual in one kernel (mlpblock.hip)
+    bool fused_tail;  // bf16 only: proj + residual + LN2 + MLP + residual (+ next block's LN1) in one kernel (tailblock.hip)
 };
 struct BlockOff {
     size_t ln1w, ln1b, wqkv, bqkv, wproj, bproj, ln2w, ln2b, w1, b1, w2, b2, wsc, bsc;
@@ -38,6 +39,7 @@ struct BlockOff {
     size_t bqkvT;  // qkv bias in T (pad-token k/v source of the LDS-DMA attention kernel)
     size_t wimg, wbias;  // fused window-block weight image + padded biases (winblock.hip), if g.fused_attn
     size_t mimg, mbias;  // fused MLP weight image + fc2 bias (mlpblock.hip), if g.fused_mlp
+    size_t timg, tvec;   // fused tail weight stream + packed vectors (tailblock.hip), if g.fused_tail
 };
 
 }  // namespace lsam
@@ -212,6 +214,9 @@ static int pack_t(lsam_hiera* h, const lsam_block_params_t* bp, const float* pat
         if (g.fused_mlp)
             LSAM_TRY(launch_pack_mlpblock(p.fc1_w, p.fc1_b, p.fc2_w, p.fc2_b, q, at<char>(arena, o.mimg),
                                           at<float>(arena, o.mbias), s));
+        if (g.fused_tail)
+            LSAM_TRY(launch_pack_tailblock(p.attn_proj_w, p.attn_proj_b, p.norm2_w, p.norm2_b, p.fc1_w, p.fc1_b, p.fc2_w,
+                                           p.fc2_b, q, at<char>(arena, o.timg), at<float>(arena, o.tvec), s));
         if (g.lora) {  // transposed copies for dX = dY . W   (frozen: no dW GEMMs exist)
             LSAM_TRY(launch_pack_matrix<T>(p.fc2_w, 1, 4 * q, 4 * q, q, at<T>(arena, o.w2T), q, s));
             LSAM_TRY(launch_pack_matrix<T>(p.fc1_w, 1, q, q, 4 * q, at<T>(arena, o.w1T), 4 * q, s));
@@ -258,6 +263,7 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
                        at<float>(arena, h->pos), e0, g0 * g0, nullptr, 0, stage_out[0], e0, nullptr, 0,
                        LSAM_EPI_OUT_F32, M0, e0, PATCH_K, s));
     float* x = stage_out[0];
+    bool xn_ready = false;   // the previous block's fused tail already wrote this block's LN1 output
     for (size_t i = 0; i < h->blk.size(); ++i) {
         const BlockGeom& g = h->blk[i];
         const BlockOff& o = h->off[i];
@@ -276,8 +282,10 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
         } else {
         // ---- norm1 (+ LoRA u columns) -----------------------------------------------------------
         T* xn = grad ? at<T>(ws, w.sv[gi].xn) : at<T>(ws, w.xn);
-        LSAM_TRY(launch_ln_fwd<T>(x, d, at<float>(arena, o.ln1w), at<float>(arena, o.ln1b), xn, g.kq,
-                                  (grad && g.need_dx) ? at<float>(ws, w.sv[gi].st1) : nullptr, Mi, d, 1e-6f, s));
+        if (!xn_ready)
+            LSAM_TRY(launch_ln_fwd<T>(x, d, at<float>(arena, o.ln1w), at<float>(arena, o.ln1b), xn, g.kq,
+                                      (grad && g.need_dx) ? at<float>(ws, w.sv[gi].st1) : nullptr, Mi, d, 1e-6f, s));
+        xn_ready = false;
         if (g.lora)
             LSAM_TRY(linear<T>(xn, g.kq, at<T>(arena, o.acat), d, nullptr, nullptr, 0, 0, nullptr, 0, xn + d, g.kq,
                                nullptr, 0, 0, Mi, AUG, d, s));
@@ -302,6 +310,21 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
         AttnArgs aa{qkv, 3 * q, at<float>(arena, o.bqkv), a, q, grad ? at<float>(ws, w.sv[gi].lse) : nullptr,
                     N, g.gin, g.gin, g.ws, g.pool, g.heads, q / g.heads, at<T>(arena, o.bqkvT)};
         LSAM_TRY(launch_attn_fwd<T>(aa, s));
+        if (g.fused_tail) {   // proj + residual + norm2 + MLP + residual (+ the next block's norm1), one kernel
+            const bool next_ln = !last && !h->blk[i + 1].fused_attn && !h->blk[i + 1].lora && h->blk[i + 1].dim == q;
+            TailBlockArgs ta{a, q, res, y, at<char>(arena, o.timg), at<float>(arena, o.tvec),
+                             next_ln ? static_cast<void*>(at<T>(ws, w.xn)) : nullptr, h->blk[next_ln ? i + 1 : i].kq,
+                             next_ln ? at<float>(arena, h->off[i + 1].ln1w) : nullptr,
+                             next_ln ? at<float>(arena, h->off[i + 1].ln1b) : nullptr, Mo, q, tailblock_chunks(q), 1e-6f};
+            LSAM_TRY(launch_tailblock(ta, s));
+            xn_ready = next_ln;
+            x = y;
+            if ((last || h->blk[i + 1].stage != g.stage) && x != stage_out[g.stage]) {
+                LSAM_HIP(hipMemcpyAsync(stage_out[g.stage], x, (size_t)Mo * q * sizeof(float), hipMemcpyDeviceToDevice, s));
+                x = stage_out[g.stage];
+            }
+            continue;
+        }
         // ---- proj + residual  (hieradet.py:79,163) -------------------------------------------------
         LSAM_TRY(linear<T>(a, q, at<T>(arena, o.wproj), q, at<float>(arena, o.bproj), res, q, 0, nullptr, 0, y, q,
                            nullptr, 0, LSAM_EPI_OUT_F32, Mo, q, q, s));
@@ -453,7 +476,8 @@ int lsam_hiera_create(const lsam_hiera_config_t* c, lsam_hiera_t** out) {
         g.kq = g.lora ? g.dim + AUG : g.dim;
         g.fused_attn = c->dtype == LSAM_BF16 && !g.lora && g.dout % g.heads == 0 &&
                        winblock_supported(g.gin, g.gin, g.ws, g.pool, g.heads, g.dout / g.heads, g.dim, g.dout);
-        g.fused_mlp = c->dtype == LSAM_BF16 && !g.lora && mlpblock_supported(g.dout);
+        g.fused_tail = c->dtype == LSAM_BF16 && !g.lora && !g.fused_attn && tailblock_supported(g.dout);
+        g.fused_mlp = c->dtype == LSAM_BF16 && !g.lora && !g.fused_tail && mlpblock_supported(g.dout);
         h->blk.push_back(g);
         dim = g.dout;
         grid = g.gout;
@@ -515,6 +539,10 @@ int lsam_hiera_create(const lsam_hiera_config_t* c, lsam_hiera_t** out) {
         if (g.fused_mlp) {
             o.mimg = b.take(mlpblock_image_bytes(g.dout));
             o.mbias = b.take(mlpblock_bias_floats(g.dout) * 4);
+        }
+        if (g.fused_tail) {
+            o.timg = b.take(tailblock_image_bytes(g.dout));
+            o.tvec = b.take(tailblock_vec_floats(g.dout) * 4);
         }
         if (g.lora) {
             o.w2T = b.take(4 * q * q * e);

@@ -91,6 +91,27 @@ int launch_pack_mlpblock(const float* w1, const float* b1, const float* w2, cons
                          float* bias_p, hipStream_t s);
 int launch_mlpblock(const MlpBlockArgs& a, hipStream_t s);
 
+// fused tail of a block: out = y + fc2(GELU(fc1(LN2(y)))), y = res + proj(a); optional next LN1  (tailblock.hip)
+struct TailBlockArgs {
+    const void* a; int lda;    // bf16 [M][lda] attention output
+    const float* res;          // fp32 [M][d] shortcut
+    float* out;                // fp32 [M][d]; may alias res
+    const void* img;           // packed chunk stream (launch_pack_tailblock)
+    const float* vec;          // packed fp32 vectors: proj bias, LN2 gamma, LN2 beta, fc2 bias
+    void* xn_next; int ldn;    // optional bf16 [M][ldn]: LayerNorm(out) with gamma_n / beta_n
+    const float* gamma_n; const float* beta_n;
+    int M, d, nch;
+    float eps;
+};
+bool tailblock_supported(int d);
+int tailblock_chunks(int d);
+size_t tailblock_image_bytes(int d);
+size_t tailblock_vec_floats(int d);
+int launch_pack_tailblock(const float* wproj, const float* bproj, const float* g2, const float* be2, const float* w1,
+                          const float* b1, const float* w2, const float* b2, int d, void* img, float* vec,
+                          hipStream_t s);
+int launch_tailblock(const TailBlockArgs& a, hipStream_t s);
+
 size_t outer_reduce_ws(int M, int C);
 template <typename T>
 int launch_outer_reduce(const T* X, int ldx, const T* Y, int ldy, int M, int C, int R, float* out,

@@ -211,3 +211,37 @@ def mlp_block_fwd(x, norm2_w, norm2_b, img, bias, eps: float = 1e-6, out=None):
     check(lib().lsam_mlp_block_fwd(ptr(x), ptr(y), ptr(norm2_w), ptr(norm2_b), ptr(img), ptr(bias), M, d, eps,
                                    stream()))
     return y
+
+
+def tail_block_pack(proj_w, proj_b, norm2_w, norm2_b, fc1_w, fc1_b, fc2_w, fc2_b):
+    """fp32 module parameters -> (streamed weight image uint8, packed fp32 vectors) of the fused block tail."""
+    params = (proj_w, proj_b, norm2_w, norm2_b, fc1_w, fc1_b, fc2_w, fc2_b)
+    _need_gpu(*params)
+    d = proj_w.shape[0]
+    nbytes, nfl = lib().lsam_tail_block_image_bytes(d), lib().lsam_tail_block_vec_floats(d)
+    if nbytes == 0:
+        raise _C.LsamError(f"fused block tail: width {d} not supported")
+    img = torch.empty(nbytes, dtype=torch.uint8, device=proj_w.device)
+    vec = torch.empty(nfl, dtype=torch.float32, device=proj_w.device)
+    args = [t.detach().float().contiguous() for t in params]
+    check(lib().lsam_tail_block_pack(*[ptr(t) for t in args], d, ptr(img), ptr(vec), stream()))
+    return img, vec
+
+
+def tail_block_fwd(a, res, img, vec, next_norm=None, eps: float = 1e-6, out=None):
+    """out = y + fc2(GELU(fc1(LN2(y)))), y = res + proj(a); with next_norm = (weight, bias) also returns
+    LayerNorm(out) in bf16 (see lsam_tail_block_fwd)."""
+    _need_gpu(a, res, img, vec)
+    assert a.dtype == torch.bfloat16 and res.dtype == torch.float32 and a.dim() == 2 and res.is_contiguous()
+    assert a.stride(1) == 1
+    M, d = res.shape
+    y = torch.empty_like(res) if out is None else out
+    xn = None
+    gw = gb = None
+    if next_norm is not None:
+        gw, gb = (t.detach().float().contiguous() for t in next_norm)
+        xn = torch.empty(M, d, dtype=torch.bfloat16, device=res.device)
+    check(lib().lsam_tail_block_fwd(ptr(a), a.stride(0), ptr(res), ptr(y), ptr(img), ptr(vec),
+                                    ptr(xn) if xn is not None else None, d, ptr(gw) if xn is not None else None,
+                                    ptr(gb) if xn is not None else None, M, d, eps, stream()))
+    return (y, xn) if next_norm is not None else y

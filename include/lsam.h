@@ -161,6 +161,24 @@ int lsam_mlp_block_pack(const float* fc1_w, const float* fc1_b, const float* fc2
 int lsam_mlp_block_fwd(const float* x, float* y, const float* norm2_w, const float* norm2_b, const void* image,
                        const float* bias_table, int M, int d, float eps, lsam_stream_t stream);
 
+/* Fused tail of a block, bf16 MFMA, in one kernel (stage-2 / stage-3 widths 224 and 448):
+ *   y   = res + proj(a)                           (hieradet.py:79,163)
+ *   out = y + fc2(GELU(fc1(LayerNorm2(y))))       (hieradet.py:165, MLP: sam2_utils.py:112-136)
+ *   xn_next = LayerNorm(out; next_norm_w, next_norm_b)   (optional: norm1 of the next block, hieradet.py:136)
+ * a bf16 [M][lda] (the attention output before attn.proj), res / out fp32 [M][d] (out may alias res),
+ * xn_next bf16 [M][ldn] or NULL.  lsam_tail_block_pack builds the streamed weight image
+ * (lsam_tail_block_image_bytes(d) bytes) and the packed vectors (lsam_tail_block_vec_floats(d) floats)
+ * from attn.proj.{weight [d][d], bias}, norm2.{weight, bias}, mlp.layers.0.{weight [4d][d], bias} and
+ * mlp.layers.1.{weight [d][4d], bias}.  Both size queries return 0 for an unsupported width. */
+size_t lsam_tail_block_image_bytes(int d);
+size_t lsam_tail_block_vec_floats(int d);
+int lsam_tail_block_pack(const float* proj_w, const float* proj_b, const float* norm2_w, const float* norm2_b,
+                         const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b, int d,
+                         void* image, float* vec, lsam_stream_t stream);
+int lsam_tail_block_fwd(const void* a, int lda, const float* res, float* out, const void* image, const float* vec,
+                        void* xn_next, int ldn, const float* next_norm_w, const float* next_norm_b, int M, int d,
+                        float eps, lsam_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Whole-trunk plan: Hiera.forward / Hiera.get_embedding (hieradet.py:284-334) with
  * LoRA_qkv on the last blocks (lora_qkv.py:102-109,162) and the autograd graph that

@@ -257,3 +257,35 @@ def test_fused_mlp_block_rejects_unsupported(ops):
     from image_segmentation_amd._C import LsamError
     with pytest.raises(LsamError):
         ops.mlp_block_pack(rnd(1792, 448).cuda(), rnd(1792).cuda(), rnd(448, 1792).cuda(), rnd(448).cuda())
+
+
+@pytest.mark.parametrize("d,M,with_next", [(448, 1000, True), (224, 777, True), (448, 128, False), (224, 4096, False)])
+def test_fused_tail_block(ops, d, M, with_next):
+    """y = res + proj(a); out = y + MLP(LN2(y)); optional LN1 of the next block (hieradet.py:79,163-165,136)."""
+    res = rnd(M, d, seed=21)
+    a = rnd(M, d, seed=22).bfloat16()
+    wp, bp = rnd(d, d, seed=23) / math.sqrt(d), 0.2 * rnd(d, seed=24)
+    g2, b2 = 1 + 0.1 * rnd(d, seed=25), 0.1 * rnd(d, seed=26)
+    w1, c1 = rnd(4 * d, d, seed=27) / math.sqrt(d), 0.2 * rnd(4 * d, seed=28)
+    w2, c2 = rnd(d, 4 * d, seed=29) / math.sqrt(4 * d), 0.2 * rnd(d, seed=30)
+    gn, bn = 1 + 0.1 * rnd(d, seed=31), 0.1 * rnd(d, seed=32)
+    y = res + a.float() @ wp.t() + bp
+    ref = y + F.gelu(F.layer_norm(y, (d,), g2, b2, 1e-6) @ w1.t() + c1) @ w2.t() + c2
+    img, vec = ops.tail_block_pack(*[t.cuda() for t in (wp, bp, g2, b2, w1, c1, w2, c2)])
+    rg = res.cuda()
+    got = ops.tail_block_fwd(a.cuda(), rg, img, vec, next_norm=(gn.cuda(), bn.cuda()) if with_next else None)
+    out, xn = got if with_next else (got, None)
+    # the residual is carried in fp32: compare the bf16-computed update
+    assert rel_err(out.cpu() - res, ref - res) < 1e-2
+    if with_next:
+        assert rel_err(xn.float().cpu(), F.layer_norm(out.cpu(), (d,), gn, bn, 1e-6)) < 5e-3
+    out2 = ops.tail_block_fwd(a.cuda(), rg, img, vec, out=rg)   # in place on the residual stream
+    assert torch.equal(out2, out)
+
+
+def test_fused_tail_block_rejects_unsupported(ops):
+    from image_segmentation_amd._C import LsamError
+    d = 112
+    with pytest.raises(LsamError):
+        ops.tail_block_pack(rnd(d, d).cuda(), rnd(d).cuda(), rnd(d).cuda(), rnd(d).cuda(), rnd(4 * d, d).cuda(),
+                            rnd(4 * d).cuda(), rnd(d, 4 * d).cuda(), rnd(d).cuda())

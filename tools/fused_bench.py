@@ -33,3 +33,15 @@ for nh, H in [(2, 256)]:
     y = torch.empty_like(x)
     us = timeit(lambda: ops.window_block_fwd(x, g, b, img, bias, nh, out=y))
     print(f"window_block nh={nh} grid={H}: {us:8.1f} us  {x.numel()*8/us/1e6:5.2f} TB/s")
+
+for d, M in [(448, 16 * 64 * 64), (224, 16 * 128 * 128)]:
+    res = torch.randn(M, d, device=dev)
+    a = torch.randn(M, d, device=dev).bfloat16()
+    r = lambda *sh: torch.randn(*sh, device=dev)
+    img, vec = ops.tail_block_pack(r(d, d) / math.sqrt(d), r(d), torch.ones(d, device=dev), torch.zeros(d, device=dev),
+                                   r(4 * d, d) / math.sqrt(d), r(4 * d), r(d, 4 * d) / math.sqrt(4 * d), r(d))
+    y = torch.empty_like(res)
+    nn_ = (torch.ones(d, device=dev), torch.zeros(d, device=dev))
+    for name, kw in (("tail", {}), ("tail+nextLN", {"next_norm": nn_})):
+        us = timeit(lambda: ops.tail_block_fwd(a, res, img, vec, out=y, **kw))
+        print(f"{name} d={d} M={M}: {us:8.1f} us  {18.0*M*d*d/us/1e6:7.1f} TF/s")
