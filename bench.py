@@ -29,6 +29,32 @@ sys.path.insert(0, REPO)
 GF_PER_FRAME = 657.4e9       # algorithmic fwd+bwd FLOPs, Hiera-B+ r=4 @1024^2
 PEAK_BF16_TFLOPS = 2500.0    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 BPLUS = dict(embed_dim=112, num_heads=2)
+# dominant kernel of the step (rocprofv3 --kernel-trace --stats, profiles/): the fused block tail of the
+# sixteen 448-wide stage-3 blocks (tailblock.hip).  liblsam tags its live event records with 9000 + d.
+DOMINANT_CFG = 9448
+DOMINANT_KERNEL = ("lsam::tailblock_kernel<14, 28, 2, 4, 1> (proj + residual + LN2 + fc1 + GELU + fc2 + residual + "
+                   "next LN1, 448 wide; algorithmic FLOPs 18 M d^2 per launch)")
+
+
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/<round>/traffic.json, written by tools/pmc_traffic.py from separate FETCH_SIZE and
+    WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py
+    cannot run the counter passes on itself; null when the file is absent."""
+    best = None
+    root = os.path.join(REPO, "profiles")
+    if os.path.isdir(root):
+        for r in sorted(os.listdir(root)):
+            f = os.path.join(root, r, "traffic.json")
+            if os.path.isfile(f):
+                best = f
+    if best is None:
+        return None
+    try:
+        with open(best) as fh:
+            return json.load(fh).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
 
 
 def build(device, rank_seed=0, lora_rank=4):
@@ -107,7 +133,7 @@ def main():
 
     enc = build(device)
     lora = [p for p in enc.parameters() if p.requires_grad]
-    reducer = LoRAGradReducer(lora)
+    reducer = LoRAGradReducer(lora).attach(enc.trunk)   # per-block buckets, all-reduce overlapped with backward
     reducer.broadcast_params(0)
     opt = torch.optim.AdamW(lora, lr=1e-4)   # config.yaml:6 of the reference
     B = args.batch
@@ -159,19 +185,25 @@ def main():
         fl = (C.c_double * cap)()
         cfg = (C.c_int * cap)()
         n = _C.lib().lsam_prof_read(cap, ms, fl, cfg, None)
-        sel = [i for i in range(n) if cfg[i] == 2224]
+        sel = [i for i in range(n) if cfg[i] == DOMINANT_CFG]
         all_ms = sum(ms[i] for i in range(n))
         tot_ms = sum(ms[i] for i in sel)
         tot_fl = sum(fl[i] for i in sel)
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "lsam::gemm2_kernel<__bf16, 2, false> (persistent 256x224 tile, LDS-DMA staged)",
+        gemm = [i for i in range(n) if cfg[i] == 2224]
+        gemm_tf = sum(fl[i] for i in gemm) / max(1e-9, sum(ms[i] for i in gemm) * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": DOMINANT_KERNEL,
                     "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": measured_traffic(),
                     "launches_per_step": len(sel) // psteps,
                     "avg_launch_us": round(1e3 * tot_ms / max(1, len(sel)), 2),
                     "avg_launch_gflop": round(tot_fl / max(1, len(sel)) / 1e9, 3),
+                    "algorithmic_hbm_bytes_per_launch": 12 * B * 64 * 64 * 448,
                     "kernel_ms_per_step": round(tot_ms / psteps, 3),
-                    "all_gemm_ms_per_step": round(all_ms / psteps, 3)}
+                    "second_kernel": {"kernel": "lsam::gemm2_kernel<__bf16, 2, false> (256x224 persistent GEMM)",
+                                      "achieved": round(gemm_tf, 2), "launches_per_step": len(gemm) // psteps,
+                                      "kernel_ms_per_step": round(sum(ms[i] for i in gemm) / psteps, 3)},
+                    "all_timed_mfma_ms_per_step": round(all_ms / psteps, 3)}
     if world > 1:
         dist.barrier()
 

@@ -72,6 +72,8 @@ def lib() -> C.CDLL:
                                          C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         L.lsam_hiera_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p),
                                           C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.lsam_hiera_backward_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                                C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         vp, i, f, l = C.c_void_p, C.c_int, C.c_float, C.c_long
         L.lsam_linear.argtypes = [i, vp, i, vp, i, vp, vp, i, i, vp, i, vp, i, vp, i, i, i, i, i, vp]
         L.lsam_pack_matrix.argtypes = [i, vp, l, l, i, i, vp, i, vp]
@@ -126,7 +128,7 @@ EXPORTED = [
     "lsam_im2col_patch", "lsam_outer_reduce_ws", "lsam_outer_reduce", "lsam_hiera_create",
     "lsam_hiera_destroy", "lsam_hiera_num_blocks", "lsam_hiera_block_info", "lsam_hiera_stage_info",
     "lsam_hiera_arena_bytes", "lsam_hiera_workspace_bytes", "lsam_hiera_pack", "lsam_hiera_pack_lora",
-    "lsam_hiera_forward", "lsam_hiera_backward",
+    "lsam_hiera_forward", "lsam_hiera_backward", "lsam_hiera_backward_block",
     "lsam_window_block_image_bytes", "lsam_window_block_bias_floats", "lsam_window_block_pack",
     "lsam_window_block_fwd", "lsam_mlp_block_image_bytes", "lsam_mlp_block_bias_floats", "lsam_mlp_block_pack",
     "lsam_mlp_block_fwd", "lsam_tail_block_image_bytes", "lsam_tail_block_vec_floats", "lsam_tail_block_pack",

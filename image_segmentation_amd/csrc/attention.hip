@@ -386,6 +386,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnArgs p, con
     }
 
     const int ntiles = (nk + KT2 - 1) / KT2;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(smem);
     issue(0);
 #pragma nounroll
     for (int tile = 0; tile < ntiles; ++tile) {
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnArgs p, con
         lds_dma_wait_barrier();   // tile landed (vmcnt(0) + barrier); everyone is done with the other buffer
         if (tile + 1 < ntiles) issue(buf ^ 1);
         const char* kb = smem + buf * STAGE;
-        const char* vb = kb + TILE_B;
+        const unsigned vb_lds = lds0 + buf * STAGE + TILE_B;
         const bool tail = __builtin_amdgcn_readfirstlane(tile * KT2 + KT2 > nk ? 1 : 0) != 0;
 
         bf16x8 kf[4][2];
@@ -453,21 +454,37 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnArgs p, con
             lrun[qt] += psum;
         }
         // ---- O^T += V^T . P^T, V^T fragments by transposing LDS reads --------------------------
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const int row = 32 * u + 4 * g + (lr >> 2), ch = 2 * dt + ((lr & 3) >> 1);
-                const char* a0 = vb + row * RB + (swz(row, ch) << 4) + (lr & 1) * 8;
-                const int row1 = row + 16;
-                const char* a1 = vb + row1 * RB + (swz(row1, ch) << 4) + (lr & 1) * 8;
-                const s16x4_t x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(a0));
-                const s16x4_t x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(a1));
-                const uint2 u0 = __builtin_bit_cast(uint2, x0), u1 = __builtin_bit_cast(uint2, x1);
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(u0.x, u0.y, u1.x, u1.y));
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt) mma16(vf, pf[qt][u], o[qt][dt]);
-            }
+        // The reads are inline asm: hipcc cannot tell the builtin transposing read apart from the LDS
+        // write of the K/V DMA issued above and puts s_waitcnt vmcnt(0) in front of it, which makes
+        // every tile wait for the NEXT tile's DMA half-way through.  Hand-ordered instead: the reads
+        // of key half u + 1 are issued before the MFMAs of half u.
+        uint2 v0[DT][2], v1[DT][2];
+#define LSAM_VREAD(dst, u)                                                                              \
+    _Pragma("unroll") for (int dt = 0; dt < DT; ++dt) {                                                 \
+        const int row = 32 * (u) + 4 * g + (lr >> 2), ch = 2 * dt + ((lr & 3) >> 1);                    \
+        const unsigned a0 = vb_lds + row * RB + (swz(row, ch) << 4) + (lr & 1) * 8;                     \
+        const int row1 = row + 16;                                                                      \
+        const unsigned a1 = vb_lds + row1 * RB + (swz(row1, ch) << 4) + (lr & 1) * 8;                   \
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst[dt][0]) : "v"(a0));                         \
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst[dt][1]) : "v"(a1));                         \
+    }
+#define LSAM_VMMA(src, u)                                                                               \
+    _Pragma("unroll") for (int dt = 0; dt < DT; ++dt) {                                                 \
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(src[dt][0].x, src[dt][0].y, src[dt][1].x, src[dt][1].y)); \
+        _Pragma("unroll") for (int qt = 0; qt < QT; ++qt) mma16(vf, pf[qt][u], o[qt][dt]);              \
+    }
+        LSAM_VREAD(v0, 0)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        LSAM_VREAD(v1, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        LSAM_VMMA(v0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        LSAM_VMMA(v1, 1)
+        __builtin_amdgcn_sched_barrier(0);
+#undef LSAM_VREAD
+#undef LSAM_VMMA
     }
 
     T* __restrict__ out = static_cast<T*>(p.out);

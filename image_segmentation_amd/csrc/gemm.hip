@@ -491,6 +491,21 @@ int prof_read(int max, float* ms, double* flops, int* cfg, int* mnk) {
     return n;
 }
 
+// generic form for the non-GEMM MFMA kernels (tailblock.hip): returns a record index or -1
+int prof_begin(hipStream_t s) {
+    if (!(g_prof_on && g_prof_n < g_prof_cap)) return -1;
+    if (hipEventRecord(g_prof[g_prof_n].e0, s) != hipSuccess) return -1;
+    return g_prof_n;
+}
+void prof_end(int rec, hipStream_t s, double flops, int cfg, int m, int n, int k) {
+    if (rec < 0 || rec != g_prof_n) return;
+    if (hipEventRecord(g_prof[rec].e1, s) != hipSuccess) return;
+    g_prof[rec].flops = flops;
+    g_prof[rec].cfg = cfg;
+    g_prof[rec].m = m; g_prof[rec].n = n; g_prof[rec].k = k;
+    ++g_prof_n;
+}
+
 template <typename T, int MT, int NT, int WM, int WN>
 static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;

@@ -361,10 +361,12 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
 
 template <typename T>
 static int backward_t(lsam_hiera* h, const float* grad_out, int N, float* const* lora_grads, void* arena, void* ws,
-                      const FwdWs& w, hipStream_t s) {
+                      const FwdWs& w, int gi_hi, int gi_lo, hipStream_t s) {
     const int r = h->cfg.lora_rank;
-    const float* dout = grad_out;
-    for (int gi = h->cfg.n_lora_blocks - 1; gi >= 0; --gi) {
+    // the last LoRA block differentiates the caller's gradient; every other block continues from the
+    // dx its successor left in the workspace (also across separate lsam_hiera_backward_block calls)
+    const float* dout = gi_hi == h->cfg.n_lora_blocks - 1 ? grad_out : at<float>(ws, w.dxprev);
+    for (int gi = gi_hi; gi >= gi_lo; --gi) {
         const int bi = h->first_lora + gi;
         const BlockGeom& g = h->blk[bi];
         const BlockOff& o = h->off[bi];
@@ -639,8 +641,30 @@ int lsam_hiera_backward(lsam_hiera_t* h, const float* grad_out, int batch, float
     LSAM_REQUIRE(workspace_bytes >= w.total, LSAM_ERR_WORKSPACE, "hiera_backward: workspace %zu < %zu bytes",
                  workspace_bytes, w.total);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (h->cfg.dtype == LSAM_BF16) return backward_t<bf16>(h, grad_out, batch, host_lora_grads, arena, workspace, w, s);
-    return backward_t<float>(h, grad_out, batch, host_lora_grads, arena, workspace, w, s);
+    const int hi = h->cfg.n_lora_blocks - 1;
+    if (h->cfg.dtype == LSAM_BF16) return backward_t<bf16>(h, grad_out, batch, host_lora_grads, arena, workspace, w, hi, 0, s);
+    return backward_t<float>(h, grad_out, batch, host_lora_grads, arena, workspace, w, hi, 0, s);
+}
+
+int lsam_hiera_backward_block(lsam_hiera_t* h, const float* grad_out, int batch, int lora_block,
+                              float* const* host_lora_grads, void* arena, void* workspace, size_t workspace_bytes,
+                              lsam_stream_t stream) {
+    LSAM_REQUIRE(h && host_lora_grads && arena && workspace, LSAM_ERR_BAD_ARG, "hiera_backward_block: null argument");
+    LSAM_REQUIRE(lora_block >= 0 && lora_block < h->cfg.n_lora_blocks, LSAM_ERR_BAD_ARG,
+                 "hiera_backward_block: block %d of %d", lora_block, h->cfg.n_lora_blocks);
+    const bool top = lora_block == h->cfg.n_lora_blocks - 1;
+    LSAM_REQUIRE(!top || (grad_out && aligned16(grad_out)), LSAM_ERR_BAD_ARG,
+                 "hiera_backward_block: the last LoRA block needs the stage-output gradient");
+    LSAM_REQUIRE(batch > 0, LSAM_ERR_BAD_ARG, "hiera_backward_block: batch");
+    for (int i = 0; i < 4; ++i)
+        LSAM_REQUIRE(host_lora_grads[4 * lora_block + i], LSAM_ERR_BAD_ARG, "hiera_backward_block: null gradient buffer %d", i);
+    const FwdWs w = plan_ws(h, batch, true);
+    LSAM_REQUIRE(workspace_bytes >= w.total, LSAM_ERR_WORKSPACE, "hiera_backward_block: workspace %zu < %zu bytes",
+                 workspace_bytes, w.total);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (h->cfg.dtype == LSAM_BF16)
+        return backward_t<bf16>(h, grad_out, batch, host_lora_grads, arena, workspace, w, lora_block, lora_block, s);
+    return backward_t<float>(h, grad_out, batch, host_lora_grads, arena, workspace, w, lora_block, lora_block, s);
 }
 
 }  // extern "C"

@@ -18,6 +18,8 @@ struct GemmArgs {
 template <typename T> int launch_gemm(const GemmArgs& a, hipStream_t s);
 int prof_arm(int capacity);
 int prof_read(int max, float* ms, double* flops, int* cfg, int* mnk);
+int prof_begin(hipStream_t s);   // live HIP-event timing of one launch while armed (bench.py's roofline)
+void prof_end(int rec, hipStream_t s, double flops, int cfg, int m, int n, int k);
 
 template <typename T>
 int launch_pack_matrix(const float* src, long src_rs, long src_cs, int rows, int cols, T* dst, int ldd,

@@ -450,8 +450,11 @@ template <int KS, int NTO, int MT, int NW, int WPC> static int launch_tail(const
     }
     const int ngroups = cdiv(a.M, 16 * MT * NW);
     const int grid = ngroups < 256 * WPC ? ngroups : 256 * WPC;   // persistent
+    const int rec = prof_begin(s);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), LDSB, s, a);
     LSAM_LAUNCH_CHECK();
+    // algorithmic work: proj 2 M d^2 + fc1 8 M d^2 + fc2 8 M d^2; cfg code 9000 + d
+    prof_end(rec, s, 18.0 * a.M * a.d * a.d, 9000 + a.d, a.M, a.d, a.d);
     return LSAM_OK;
 }
 

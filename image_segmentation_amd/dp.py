@@ -1,12 +1,15 @@
-"""Data-parallel step for LoRA fine-tuning: one process per GPU, frames sharded by rank,
-and ONE exchange per step -- a mean all-reduce of the LoRA gradients only, as one flat fp32
-buffer (28,672 floats at r=4).  This replaces DistributedDataParallel's reducer
-(train_lora_sam.py:126,172): with every non-LoRA parameter frozen the
-reducer's single bucket holds exactly these eight tensors.
+"""Data-parallel step for LoRA fine-tuning: one process per GPU, frames sharded by rank, and ONE
+exchange step per iteration -- a mean all-reduce of the LoRA gradients only (28,672 fp32 values at
+r=4).  This replaces DistributedDataParallel's reducer (train_lora_sam.py:126,172; SURVEY.md
+section 2b): with every non-LoRA parameter frozen the reducer's traffic is exactly these tensors.
 
-The message is ~112 KiB, so the collective is latency-bound, not link-bound: it is issued as a
-single RCCL all-reduce (backend "nccl" on ROCm) right after the backward call; on CPU the
-same code runs over gloo (tests/test_dp_cpu.py)."""
+The gradients travel in buckets of one LoRA block each (4 tensors, 56 KiB at r=4), in the order the
+backward produces them.  `attach(trunk)` registers a hook with the trunk so that a block's bucket is
+all-reduced (RCCL, backend "nccl" on ROCm, on its own stream) as soon as that block's backward is
+enqueued, overlapping the rest of the backward; `reduce()` then only waits, scales by 1/world and
+writes the result to `.grad`.  Without `attach` (or for gradients the hook never saw) `reduce()`
+all-reduces the buckets itself.  At this size the collective is latency-bound, not link-bound, so
+the buckets are not split further.  On CPU the same code runs over gloo (tests/test_dp_cpu.py)."""
 from __future__ import annotations
 
 from typing import Iterable, List, Optional
@@ -15,23 +18,48 @@ import torch
 import torch.distributed as dist
 
 
+class _Bucket:
+    def __init__(self, params, flat):
+        self.params = params
+        self.flat = flat
+        self.views = []
+        o = 0
+        for p in params:
+            self.views.append(flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+        self.work = None      # in-flight all-reduce started by the hook
+        self.filled = False   # flat holds this step's local gradients
+
+
 class LoRAGradReducer:
-    def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None,
+                 tensors_per_bucket: int = 4):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("LoRAGradReducer: no trainable parameters")
+        if tensors_per_bucket < 1:
+            raise ValueError("LoRAGradReducer: tensors_per_bucket must be positive")
         self.group = group
         self.numel = sum(p.numel() for p in self.params)
         p0 = self.params[0]
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
-        self.views = []
+        self.buckets: List[_Bucket] = []
         o = 0
-        for p in self.params:
-            self.views.append(self.flat[o:o + p.numel()].view_as(p))
-            o += p.numel()
+        for i in range(0, len(self.params), tensors_per_bucket):
+            ps = self.params[i:i + tensors_per_bucket]
+            n = sum(p.numel() for p in ps)
+            self.buckets.append(_Bucket(ps, self.flat[o:o + n]))
+            o += n
+        self.views = [v for b in self.buckets for v in b.views]
+        self._by_first = {id(b.params[0]): b for b in self.buckets}
 
     def world_size(self) -> int:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def attach(self, trunk) -> "LoRAGradReducer":
+        """Overlap mode: the trunk's backward hands each LoRA block's gradients to on_bucket()."""
+        trunk.set_grad_bucket_hook(self.on_bucket)
+        return self
 
     @torch.no_grad()
     def broadcast_params(self, src: int = 0):
@@ -44,14 +72,32 @@ class LoRAGradReducer:
         torch._foreach_copy_([p.data for p in self.params], self.views)
 
     @torch.no_grad()
+    def on_bucket(self, params, grads):
+        """Called from the backward (autograd thread) once the gradients of `params` are enqueued on
+        the current stream: stage them in the bucket and start its all-reduce without waiting."""
+        b = self._by_first.get(id(params[0]))
+        if b is None or len(params) != len(b.params) or any(p is not q for p, q in zip(params, b.params)):
+            return   # not one of our buckets: reduce() falls back to .grad
+        if self.world_size() == 1:
+            return
+        torch._foreach_copy_(b.views, list(grads))
+        b.filled = True
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    @torch.no_grad()
     def reduce(self):
         """grads <- mean over ranks.  Missing grads count as zero (DDP semantics)."""
         ws = self.world_size()
         if ws == 1:
             return
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
-        torch._foreach_copy_(self.views, grads)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        for b in reversed(self.buckets):   # the order the backward produced (and launched) them
+            if not b.filled:
+                grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b.params]
+                torch._foreach_copy_(b.views, grads)
+                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        for b in reversed(self.buckets):
+            b.work.wait()
+            b.work, b.filled = None, False
         self.flat.mul_(1.0 / ws)
         for p, v in zip(self.params, self.views):
             if p.grad is None:

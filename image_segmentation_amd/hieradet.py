@@ -195,6 +195,7 @@ class _Plan:
         self.arena = torch.empty(lib().lsam_hiera_arena_bytes(h), dtype=torch.uint8, device=device)
         self.packed_sig = None
         self.ws_pool = {}
+        self.bucket_hook = trunk._grad_bucket_hook
 
     def __del__(self):
         try:
@@ -281,6 +282,7 @@ class _TrunkFn(torch.autograd.Function):
         if with_grad:
             ctx.ws = ws
             ctx.lora_shapes = [tuple(t.shape) for t in lora]
+            ctx.lora_params = lora   # the Parameters themselves: handed to the gradient-bucket hook
             ctx.mark_non_differentiable(*outs[:-1])
         else:
             plan.release(N, False, ws)
@@ -299,8 +301,17 @@ class _TrunkFn(torch.autograd.Function):
         out = [torch.empty(s, dtype=torch.float32, device=g.device) for s in ctx.lora_shapes]
         arr = (C.c_void_p * len(out))(*[o.data_ptr() for o in out])
         # the plan's LoRA-dependent packed operands still hold this step's factors
-        check(lib().lsam_hiera_backward(plan.h, g.data_ptr(), ctx.N, arr, plan.arena.data_ptr(),
-                                        ctx.ws.data_ptr(), ctx.ws.numel(), stream()))
+        hook = plan.bucket_hook
+        if hook is None:
+            check(lib().lsam_hiera_backward(plan.h, g.data_ptr(), ctx.N, arr, plan.arena.data_ptr(),
+                                            ctx.ws.data_ptr(), ctx.ws.numel(), stream()))
+        else:
+            # one LoRA block at a time, last first: each block's four gradients are handed to the hook
+            # (dp.LoRAGradReducer starts their all-reduce) while the next block's backward is enqueued
+            for bi in range(plan.n_lora - 1, -1, -1):
+                check(lib().lsam_hiera_backward_block(plan.h, g.data_ptr(), ctx.N, bi, arr, plan.arena.data_ptr(),
+                                                      ctx.ws.data_ptr(), ctx.ws.numel(), stream()))
+                hook(list(ctx.lora_params[4 * bi: 4 * bi + 4]), out[4 * bi: 4 * bi + 4])
         plan.release(ctx.N, True, ctx.ws)
         ctx.ws = None
         return (None, None, None) + tuple(out)
@@ -358,6 +369,15 @@ class Hiera(nn.Module):
             self.load_state_dict(chkpt, strict=False)
         self.compute_dtype: Optional[torch.dtype] = None
         self._plans = {}
+        self._grad_bucket_hook = None
+
+    def set_grad_bucket_hook(self, hook):
+        """hook(params, grads) is called from the backward as soon as one LoRA block's gradients are
+        enqueued (last block first); None restores the single-call backward.  Used by
+        dp.LoRAGradReducer.attach to overlap the gradient all-reduce with the rest of the backward."""
+        self._grad_bucket_hook = hook
+        for plan in self._plans.values():
+            plan.bucket_hook = hook
 
     # -- constant per shape: computed once per plan (hieradet.py:273-281) --------------------
     def _get_pos_embed(self, hw: Tuple[int, int]) -> torch.Tensor:

@@ -250,6 +250,15 @@ int lsam_hiera_forward(lsam_hiera_t* h, const float* img, int batch, float* cons
 int lsam_hiera_backward(lsam_hiera_t* h, const float* grad_out, int batch,
                         float* const* host_lora_grads, void* arena, void* workspace,
                         size_t workspace_bytes, lsam_stream_t stream);
+/* One LoRA block of lsam_hiera_backward at a time, last block first (lora_block = n_lora_blocks-1 ... 0):
+ * lets the caller start the all-reduce of a block's four gradients while the next block's backward
+ * runs (DistributedDataParallel's bucketed overlap, train_lora_sam.py:126,172).  grad_out is read by
+ * the last block only; the others continue from the dx their successor left in the workspace, so the
+ * calls must be made in descending order on one stream with the same workspace.  host_lora_grads is
+ * the same 4*n_lora_blocks table as for lsam_hiera_backward; only entries 4*lora_block.. are written. */
+int lsam_hiera_backward_block(lsam_hiera_t* h, const float* grad_out, int batch, int lora_block,
+                              float* const* host_lora_grads, void* arena, void* workspace, size_t workspace_bytes,
+                              lsam_stream_t stream);
 
 #ifdef __cplusplus
 }

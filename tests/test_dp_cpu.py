@@ -37,7 +37,7 @@ def _frames(first, n):
     return synth_frames(first + n, IMG, 0)[first:]      # frame i is the same tensor on every rank
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, overlap):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(2)
@@ -53,7 +53,19 @@ def _worker(rank, world, port, q):
                 for prm in params:
                     prm.add_(1.0)
         red = LoRAGradReducer(params)
+        assert len(red.buckets) == 2 and all(len(b.params) == 4 for b in red.buckets)   # one bucket per LoRA block
         red.broadcast_params(0)             # ... and must end up with rank 0's
+        if overlap:
+            # what Hiera's backward does through the hook that attach() registers: the LAST block's four
+            # gradients first, then the block before it; autograd assigns .grad only afterwards
+            local = [prm.grad for prm in params]
+            for prm in params:
+                prm.grad = None
+            for lo in (4, 0):
+                red.on_bucket(params[lo:lo + 4], local[lo:lo + 4])
+            assert all(b.work is not None for b in red.buckets)
+            for prm, g in zip(params, local):
+                prm.grad = g
         red.reduce()
         q.put((rank, {n: prm.grad.clone().numpy() for n, prm in zip(names, params)},
                {n: prm.detach().clone().numpy() for n, prm in zip(names, params)}))
@@ -68,12 +80,13 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_lora_grad_allreduce_matches_global_batch():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_rank_lora_grad_allreduce_matches_global_batch(overlap):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, overlap)) for r in range(world)]
     for pr in procs:
         pr.start()
     got = [q.get(timeout=240) for _ in range(world)]

@@ -180,3 +180,39 @@ def test_fails_loudly_without_gpu_tensors():
     enc = make_encoder(TINY, device="cpu")
     with pytest.raises(LsamError):
         enc(torch.zeros(1, 3, 256, 256))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_per_block_backward_with_bucket_hook_matches_single_call(dtype):
+    """lsam_hiera_backward_block (one LoRA block per call, last first, the path dp.LoRAGradReducer.attach
+    switches on) must give bit-identical gradients to the single lsam_hiera_backward call, and hand the
+    buckets to the hook in the order DDP's reducer would see them (train_lora_sam.py:126,172)."""
+    from image_segmentation_amd.synth import synth_frames
+    img = synth_frames(2, 256, 0, device="cuda")
+
+    def step(enc):
+        for p in enc.parameters():
+            p.grad = None
+        enc.trunk.compute_dtype = dtype
+        fpn_loss(enc(img)).backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().clone() for n, p in enc.named_parameters() if p.requires_grad}
+
+    enc = make_encoder(TINY)
+    ref = step(enc)
+    calls = []
+    enc.trunk.set_grad_bucket_hook(lambda params, grads: calls.append((params, [g.clone() for g in grads])))
+    got = step(enc)
+    assert len(calls) == 2 and all(len(p) == 4 for p, _ in calls)
+    blocks = enc.trunk.blocks
+    assert calls[0][0][0] is blocks[-1].attn.qkv.linear_a_q.weight      # last block first
+    assert calls[1][0][0] is blocks[-2].attn.qkv.linear_a_q.weight
+    for n in ref:
+        assert torch.equal(got[n], ref[n]), n
+    for params, grads in calls:                                          # the hook saw the final values
+        for p, g in zip(params, grads):
+            assert torch.equal(p.grad, g)
+    enc.trunk.set_grad_bucket_hook(None)
+    again = step(enc)
+    for n in ref:
+        assert torch.equal(again[n], ref[n]), n
