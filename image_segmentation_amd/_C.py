@@ -82,6 +82,7 @@ def lib() -> C.CDLL:
         L.lsam_attention_fwd.argtypes = [i, vp, i, vp, vp, vp, i, vp, i, i, i, i, i, i, i, vp]
         L.lsam_attention_bwd.argtypes = [i, vp, i, vp, vp, i, vp, vp, i, i, i, i, i, i, i, vp]
         L.lsam_maxpool2x2.argtypes = [vp, vp, i, i, i, i, vp]
+        L.lsam_spatial_mean.argtypes = [vp, vp, i, i, i, vp]
         L.lsam_cast.argtypes = [i, vp, i, vp, i, i, i, vp]
         L.lsam_im2col_patch.argtypes = [i, vp, vp, i, i, i, vp]
         L.lsam_outer_reduce.argtypes = [i, vp, i, vp, i, i, i, i, vp, l, l, vp, vp]
@@ -124,7 +125,7 @@ def dtype_code(dt: torch.dtype) -> int:
 
 EXPORTED = [
     "lsam_last_error", "lsam_version", "lsam_prof_arm", "lsam_prof_read", "lsam_linear", "lsam_pack_matrix", "lsam_layernorm_fwd",
-    "lsam_layernorm_bwd", "lsam_attention_fwd", "lsam_attention_bwd", "lsam_maxpool2x2", "lsam_cast",
+    "lsam_layernorm_bwd", "lsam_attention_fwd", "lsam_attention_bwd", "lsam_maxpool2x2", "lsam_spatial_mean", "lsam_cast",
     "lsam_im2col_patch", "lsam_outer_reduce_ws", "lsam_outer_reduce", "lsam_hiera_create",
     "lsam_hiera_destroy", "lsam_hiera_num_blocks", "lsam_hiera_block_info", "lsam_hiera_stage_info",
     "lsam_hiera_arena_bytes", "lsam_hiera_workspace_bytes", "lsam_hiera_pack", "lsam_hiera_pack_lora",

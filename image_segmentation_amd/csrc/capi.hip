@@ -76,6 +76,9 @@ int lsam_attention_bwd(int dtype, const void* qkv, int ldqkv, const float* bias,
     DISPATCH(dtype, launch_attn_bwd<float>(a, s), launch_attn_bwd<bf16>(a, s));
 }
 
+int lsam_spatial_mean(const float* x, float* out, int N, int HW, int C, lsam_stream_t stream) {
+    return launch_spatial_mean(x, out, N, HW, C, static_cast<hipStream_t>(stream));
+}
 int lsam_maxpool2x2(const float* x, float* out, int N, int H, int W, int C, lsam_stream_t stream) {
     return launch_maxpool2x2(x, out, N, H, W, C, static_cast<hipStream_t>(stream));
 }

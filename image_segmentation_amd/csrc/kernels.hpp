@@ -53,6 +53,7 @@ struct AttnBwdArgs {
 template <typename T> int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t s);
 
 int launch_maxpool2x2(const float* x, float* out, int N, int H, int W, int C, hipStream_t s);
+int launch_spatial_mean(const float* x, float* out, int N, int HW, int C, hipStream_t s);
 template <typename T>
 int launch_cast(const float* src, int lds, T* dst, int ldd, int rows, int cols, hipStream_t s);
 template <typename T>

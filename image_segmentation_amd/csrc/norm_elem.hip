@@ -228,6 +228,35 @@ int launch_maxpool2x2(const float* x, float* out, int N, int H, int W, int C, hi
 }
 
 // ---------------------------------------------------------------------------------------------
+// per-frame spatial mean of an NHWC map: out[n][c] = mean_{hw} x[n][hw][c]  (the pooled 896-d
+// stage-4 feature of the feature-extraction pass, train_cl_kmean.py:189-207 / hieradet.py:284-302)
+// One workgroup = one frame x 64 channels: 4 waves stride over the tokens, lanes over channels
+// (256-byte coalesced rows), fixed-order LDS reduction -> deterministic.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spatial_mean_kernel(const float* __restrict__ x, float* __restrict__ out, int HW,
+                                                           int C) {
+    __shared__ float part[4][64];
+    const int n = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < C) {
+        const float* p = x + (size_t)n * HW * C + c;
+        for (int t = w; t < HW; t += 4) s += p[(size_t)t * C];
+    }
+    part[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < C)
+        out[(size_t)n * C + c] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x])) / (float)HW;
+}
+
+int launch_spatial_mean(const float* x, float* out, int N, int HW, int C, hipStream_t s) {
+    LSAM_REQUIRE(x && out && N > 0 && HW > 0 && C > 0, LSAM_ERR_BAD_ARG, "spatial_mean: null/empty");
+    LSAM_REQUIRE(N <= 65535, LSAM_ERR_UNSUPPORTED, "spatial_mean: at most 65535 frames per call");
+    hipLaunchKernelGGL(spatial_mean_kernel, dim3(cdiv(C, 64), N), dim3(256), 0, s, x, out, HW, C);
+    LSAM_LAUNCH_CHECK();
+    return LSAM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // fp32 -> T
 // ---------------------------------------------------------------------------------------------
 template <typename T>

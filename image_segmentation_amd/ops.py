@@ -129,6 +129,16 @@ def maxpool2x2(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def spatial_mean(x: torch.Tensor) -> torch.Tensor:
+    """fp32 NHWC [N,H,W,C] -> [N,C] mean over the grid (see lsam_spatial_mean)."""
+    _need_gpu(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    N, H, W, Cc = x.shape
+    out = torch.empty(N, Cc, dtype=torch.float32, device=x.device)
+    check(lib().lsam_spatial_mean(ptr(x), ptr(out), N, H * W, Cc, stream()))
+    return out
+
+
 def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     _need_gpu(x)
     rows, cols, lds = _rows2d(x)

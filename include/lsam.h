@@ -115,6 +115,11 @@ int lsam_attention_bwd(int dtype, const void* qkv, int ldqkv, const float* bias,
 /* out[n,h/2,w/2,:] = max over the 2x2 block (do_pool on the shortcut, hieradet.py:140). fp32 NHWC. */
 int lsam_maxpool2x2(const float* x, float* out, int N, int H, int W, int C, lsam_stream_t stream);
 
+/* out[n][c] = mean over the HW tokens of x[n][hw][c] (fp32 NHWC): the per-frame pooled embedding of the
+ * feature-extraction pass over Hiera.get_embedding's last stage (hieradet.py:284-302), the quantity the
+ * reference's nearest-domain LoRA selection compares (train_cl_kmean.py:189-207). Deterministic. */
+int lsam_spatial_mean(const float* x, float* out, int N, int HW, int C, lsam_stream_t stream);
+
 /* fp32 -> T copy of a [rows][cols] matrix (ld in elements). */
 int lsam_cast(int dtype, const float* src, int lds, void* dst, int ldd, int rows, int cols,
               lsam_stream_t stream);
