@@ -514,12 +514,15 @@ template <int QT> static int attn2_launch(const AttnArgs& a, int nqb, hipStream_
     return LSAM_OK;
 }
 
+// HDP = head_dim padded to the LDS row the kernel is built for: 64 (Hiera-T/S/B+: 56 ... 64) or 128
+// (Hiera-L: 72).  Rows stay a power-of-two number of 16-byte chunks, which the XOR swizzle needs.
 template <typename T, int QT>
 static int attn_fwd_launch(const AttnArgs& a, int nwaves, int nqb, hipStream_t s) {
     const WinGeom G = make_geom(a.H, a.W, a.ws, a.pool);
     const float c = (1.0f / sqrtf((float)a.hd)) * 1.4426950408889634f;
     const dim3 grid(a.N * G.nwy * G.nwx, a.nh, nqb), blk(64 * nwaves);
-    hipLaunchKernelGGL((attn_fwd_kernel<T, QT, 64>), grid, blk, 0, s, a, c);
+    if (a.hd <= 64) hipLaunchKernelGGL((attn_fwd_kernel<T, QT, 64>), grid, blk, 0, s, a, c);
+    else hipLaunchKernelGGL((attn_fwd_kernel<T, QT, 128>), grid, blk, 0, s, a, c);
     LSAM_LAUNCH_CHECK();
     return LSAM_OK;
 }
@@ -528,7 +531,7 @@ template <typename T> int launch_attn_fwd(const AttnArgs& a, hipStream_t s) {
     constexpr int EPC = Tr<T>::EPC;
     LSAM_REQUIRE(a.qkv && a.bias && a.out, LSAM_ERR_BAD_ARG, "attention: null pointer");
     LSAM_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.nh > 0 && a.hd > 0, LSAM_ERR_BAD_ARG, "attention: empty shape");
-    LSAM_REQUIRE(a.hd % 8 == 0 && a.hd <= 64, LSAM_ERR_UNSUPPORTED, "attention: head_dim %d (need %%8==0, <=64)", a.hd);
+    LSAM_REQUIRE(a.hd % 8 == 0 && a.hd <= 128, LSAM_ERR_UNSUPPORTED, "attention: head_dim %d (need %%8==0, <=128)", a.hd);
     LSAM_REQUIRE(a.pool == 1 || a.pool == 2, LSAM_ERR_UNSUPPORTED, "attention: q-pool stride %d", a.pool);
     LSAM_REQUIRE(a.ws >= 0 && (a.pool == 1 || (a.ws > 0 && a.ws % 2 == 0 && a.H % 2 == 0 && a.W % 2 == 0)),
                  LSAM_ERR_UNSUPPORTED, "attention: pooled blocks need an even window and grid (ws=%d)", a.ws);
@@ -539,7 +542,7 @@ template <typename T> int launch_attn_fwd(const AttnArgs& a, hipStream_t s) {
     const WinGeom G = make_geom(a.H, a.W, a.ws, a.pool);
     const int max_nq = G.qh * G.qw;
     if constexpr (sizeof(T) == 2) {
-        if (a.bias_t && G.wsh * G.wsw >= 128 && max_nq >= 32 && a.ldqkv % 8 == 0) {
+        if (a.bias_t && a.hd <= 64 && G.wsh * G.wsw >= 128 && max_nq >= 32 && a.ldqkv % 8 == 0) {
             if (max_nq > 64) return attn2_launch<4>(a, cdiv(max_nq, 256), s);
             return attn2_launch<1>(a, 1, s);
         }
@@ -934,7 +937,8 @@ template <typename T> int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t s) {
     LSAM_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.nh > 0, LSAM_ERR_BAD_ARG, "attention_bwd: empty shape");
     LSAM_REQUIRE(a.ws > 0 && a.ws * a.ws <= BW_NK, LSAM_ERR_UNSUPPORTED,
                  "attention_bwd: window %d not supported (need 0 < ws*ws <= %d)", a.ws, BW_NK);
-    LSAM_REQUIRE(a.hd > 0 && a.hd <= 64, LSAM_ERR_UNSUPPORTED, "attention_bwd: head_dim %d", a.hd);
+    LSAM_REQUIRE(a.hd > 0 && a.hd <= 64, LSAM_ERR_UNSUPPORTED,
+                 "attention_bwd: head_dim %d > 64 (Hiera-L) has a forward path only", a.hd);
     LSAM_REQUIRE(a.ldqkv >= 3 * a.nh * a.hd && a.lddqkv >= 3 * a.nh * a.hd && a.lddo >= a.nh * a.hd,
                  LSAM_ERR_BAD_ARG, "attention_bwd: leading dimensions");
     const int nwy = cdiv(a.H, a.ws), nwx = cdiv(a.W, a.ws);

@@ -488,8 +488,8 @@ int lsam_hiera_create(const lsam_hiera_config_t* c, lsam_hiera_t** out) {
     int rc = LSAM_OK;
     for (int i = 0; i < depth && rc == LSAM_OK; ++i) {
         const BlockGeom& g = h->blk[i];
-        if (g.dout % g.heads != 0 || (g.dout / g.heads) % 8 != 0 || g.dout / g.heads > 64) {
-            set_error("hiera_create: block %d head_dim %d unsupported (need %%8==0, <=64)", i, g.dout / g.heads);
+        if (g.dout % g.heads != 0 || (g.dout / g.heads) % 8 != 0 || g.dout / g.heads > 128) {
+            set_error("hiera_create: block %d head_dim %d unsupported (need %%8==0, <=128)", i, g.dout / g.heads);
             rc = LSAM_ERR_UNSUPPORTED;
         } else if (g.pool == 2 && (g.ws <= 0 || g.ws % 2 || g.gin % 2)) {
             set_error("hiera_create: q-pool block %d needs an even window and grid", i);

@@ -60,7 +60,7 @@ class MLP(nn.Module):
 def _compute_dtype(explicit: Optional[torch.dtype]) -> torch.dtype:
     if explicit is not None:
         return explicit
-    if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16:
+    if torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16:
         return torch.bfloat16
     return torch.float32
 

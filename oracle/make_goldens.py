@@ -34,6 +34,9 @@ GOLD = os.path.join(REPO, "tests", "golden")
 
 TINY = dict(embed_dim=56, num_heads=1, stages=(2, 2, 3, 3), global_att_blocks=(5,))
 BPLUS = dict(embed_dim=112, num_heads=2)  # sam2_model.py:12
+# Hiera-L (configs/sam2.1/sam2.1_hiera_l.yaml:11-16): head_dim 72, window_spec (8,4,16,8), r = 8
+LARGE = dict(embed_dim=144, num_heads=2, stages=(2, 6, 36, 4), global_att_blocks=(23, 33, 43), window_spec=(8, 4, 16, 8))
+TINY_L = dict(embed_dim=72, num_heads=1, stages=(2, 2, 3, 3), global_att_blocks=(5,), window_spec=(8, 4, 16, 8))
 
 
 def import_reference():
@@ -186,10 +189,20 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     R = import_reference()
-    micro_lora_slice(R)
-    micro_blocks(R)
-    run(R, TINY, rank=4, seed=0, n=2, size=256, tag="tiny_r4", full=True)
-    run(R, BPLUS, rank=4, seed=0, n=1, size=1024, tag="bplus_r4_1024", full=False)
+    only = set(sys.argv[1:])      # optional: regenerate just the named fixtures
+    want = lambda tag: not only or tag in only
+    if want("micro_lora_slice"):
+        micro_lora_slice(R)
+    if want("micro_blocks"):
+        micro_blocks(R)
+    if want("tiny_r4"):
+        run(R, TINY, rank=4, seed=0, n=2, size=256, tag="tiny_r4", full=True)
+    if want("bplus_r4_1024"):
+        run(R, BPLUS, rank=4, seed=0, n=1, size=1024, tag="bplus_r4_1024", full=False)
+    if want("tinyL_r8"):
+        run(R, TINY_L, rank=8, seed=0, n=2, size=256, tag="tinyL_r8", full=True)
+    if want("large_r8_1024"):
+        run(R, LARGE, rank=8, seed=0, n=1, size=1024, tag="large_r8_1024", full=False)
 
 
 if __name__ == "__main__":

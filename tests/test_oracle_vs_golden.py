@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import BPLUS, TINY, load_golden, rel_err
+from conftest import BPLUS, TINY, TINY_L, load_golden, rel_err
 from image_segmentation_amd.synth import synth_frames, synth_tensor
 from oracle import hiera_oracle as O
 from oracle.params import make_params
@@ -42,6 +42,22 @@ def test_tiny_matches_reference():
             assert rel_err(t.grad, g["grad." + name]) < 1e-4, name
             n += 1
     assert n == 8
+
+
+def test_tiny_large_family_matches_reference():
+    """Hiera-L geometry in miniature: head_dim 72, window_spec (8,4,16,8), r = 8 (BASELINE.json configs[3])."""
+    g = load_golden("tinyL_r8")
+    spec, p, blocks, out, loss = _run(TINY_L, 2, 256, rank=8)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    for i, b in enumerate(blocks):
+        assert rel_err(b.detach()[:, ::4, ::4, ::2], g[f"block{i}.sub"]) < TOL, i
+    assert rel_err(out["backbone_fpn"][2].detach(), g["fpn2"]) < TOL
+    n = 0
+    for name, t in p.items():
+        if t.requires_grad:
+            assert rel_err(t.grad, g["grad." + name]) < 1e-4, name
+            n += t.numel()
+    assert n == 2 * 4 * 8 * 576     # two LoRA blocks x (A_q, B_q, A_v, B_v) x r x dim
 
 
 @pytest.mark.timeout(600)
