@@ -60,7 +60,12 @@ __host__ __device__ inline WinGeom make_geom(int H, int W, int ws, int pool) {
     return g;
 }
 
-template <typename T, int QT, int HDP>
+// NWH = 1: the waves of a workgroup split the queries of one (window, head).
+// NWH = 4: windows with at most 16 queries (Hiera stage 2 and its transitions): every wave takes its
+//          own HEAD of the same window, with a private K/V tile in LDS -- four times fewer, four times
+//          larger workgroups than one 64-thread workgroup per (window, head), and the four heads' q/k/v
+//          slices of a token are adjacent in memory.
+template <typename T, int QT, int HDP, int NWH>
 __global__ void attn_fwd_kernel(const AttnArgs p, const float c_log2) {
     constexpr int EPC = Tr<T>::EPC, CPF = Tr<T>::CPF;
     constexpr int KSD = HDP / 32, DT = HDP / 16;
@@ -68,19 +73,25 @@ __global__ void attn_fwd_kernel(const AttnArgs p, const float c_log2) {
     constexpr int VRB = VtLayout<T>::RB;
     using frag = typename Tr<T>::frag;
 
-    __shared__ __attribute__((aligned(16))) char ks_[KT * RB];
-    __shared__ __attribute__((aligned(16))) char vt_[HDP * VRB];
+    __shared__ __attribute__((aligned(16))) char ks_all[NWH * KT * RB];
+    __shared__ __attribute__((aligned(16))) char vt_all[NWH * HDP * VRB];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+    const int lane = threadIdx.x & 63, wave_id = threadIdx.x >> 6;
+    const int hw = NWH > 1 ? wave_id : 0;                      // head slot of this wave
+    const int wave = NWH > 1 ? 0 : wave_id;                    // query-tile slot of this wave
+    const int tid = NWH > 1 ? lane : (int)threadIdx.x, nthr = NWH > 1 ? 64 : (int)blockDim.x;   // staging team
+    char* ks_ = ks_all + hw * KT * RB;
+    char* vt_ = vt_all + hw * HDP * VRB;
     const int g = lane >> 4, lr = lane & 15;
     const int H = p.H, W = p.W, nh = p.nh, hd = p.hd, dout = nh * hd;
     const WinGeom G = make_geom(H, W, p.ws, p.pool);
-    const int h = blockIdx.y;
+    const bool hok = (int)blockIdx.y * NWH + hw < nh;          // idle head slots still join the barriers
+    const int h = hok ? blockIdx.y * NWH + hw : nh - 1;
     const int win = blockIdx.x % (G.nwy * G.nwx), n = blockIdx.x / (G.nwy * G.nwx);
     const int wy = win / G.nwx, wx = win % G.nwx;
     const int rh = min(G.qh, G.Ho - wy * G.qh), rw = min(G.qw, G.Wo - wx * G.qw);
     const int nq = rh * rw, nk = G.wsh * G.wsw;
-    const int qblock = (blockDim.x >> 6) * QT * 16;
+    const int qblock = (NWH > 1 ? 1 : (int)(blockDim.x >> 6)) * QT * 16;
     const int qbase = blockIdx.z * qblock;
     if (qbase >= nq) return;  // uniform for the workgroup, before any barrier
 
@@ -94,7 +105,7 @@ __global__ void attn_fwd_kernel(const AttnArgs p, const float c_log2) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         const int qi = qbase + (wave * QT + qt) * 16 + lr;
-        const bool qv = qi < nq;
+        const bool qv = qi < nq && hok;
         const int iy = qv ? qi / rw : 0, ix = qv ? qi % rw : 0;
         qtok[qt] = qv ? (int)(((size_t)n * G.Ho + (wy * G.qh + iy)) * G.Wo + (wx * G.qw + ix)) : -1;
 #pragma unroll
@@ -520,9 +531,15 @@ template <typename T, int QT>
 static int attn_fwd_launch(const AttnArgs& a, int nwaves, int nqb, hipStream_t s) {
     const WinGeom G = make_geom(a.H, a.W, a.ws, a.pool);
     const float c = (1.0f / sqrtf((float)a.hd)) * 1.4426950408889634f;
+    if (QT == 1 && nwaves == 1 && nqb == 1 && a.nh >= 2 && a.hd <= 64) {   // <= 16 queries: one wave per head
+        const dim3 grid(a.N * G.nwy * G.nwx, cdiv(a.nh, 4), 1), blk(256);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, 1, 64, 4>), grid, blk, 0, s, a, c);
+        LSAM_LAUNCH_CHECK();
+        return LSAM_OK;
+    }
     const dim3 grid(a.N * G.nwy * G.nwx, a.nh, nqb), blk(64 * nwaves);
-    if (a.hd <= 64) hipLaunchKernelGGL((attn_fwd_kernel<T, QT, 64>), grid, blk, 0, s, a, c);
-    else hipLaunchKernelGGL((attn_fwd_kernel<T, QT, 128>), grid, blk, 0, s, a, c);
+    if (a.hd <= 64) hipLaunchKernelGGL((attn_fwd_kernel<T, QT, 64, 1>), grid, blk, 0, s, a, c);
+    else hipLaunchKernelGGL((attn_fwd_kernel<T, QT, 128, 1>), grid, blk, 0, s, a, c);
     LSAM_LAUNCH_CHECK();
     return LSAM_OK;
 }
