@@ -121,7 +121,7 @@ static FwdWs plan_ws(const lsam_hiera* h, int N, bool with_grad) {
         w.dqkv = b.take(M * (3 * d + AUG) * e);
         w.dxn = b.take(M * d * sizeof(float));
         w.dxprev = b.take(M * d * sizeof(float));
-        w.partial = b.take(outer_reduce_ws((int)M, (int)d));
+        w.partial = b.take(4 * outer_reduce_ws((int)M, (int)d));
     }
     w.total = b.cur;
     return w;
@@ -400,10 +400,10 @@ static int backward_t(lsam_hiera* h, const float* grad_out, int N, float* const*
         // LoRA gradients (token reductions): dB = dq^T u, dA = t^T xn
         void* part = at<char>(ws, w.partial);
         float* const* G = lora_grads + 4 * gi;
-        LSAM_TRY(launch_outer_reduce<T>(xn, g.kq, dqkv + 3 * d, ldq, M, d, r, G[0], 1, d, part, s));            // dA_q
-        LSAM_TRY(launch_outer_reduce<T>(dqkv, ldq, xn + d, g.kq, M, d, r, G[1], r, 1, part, s));                // dB_q
-        LSAM_TRY(launch_outer_reduce<T>(xn, g.kq, dqkv + 3 * d + 16, ldq, M, d, r, G[2], 1, d, part, s));       // dA_v
-        LSAM_TRY(launch_outer_reduce<T>(dqkv + 2 * d, ldq, xn + d + 16, g.kq, M, d, r, G[3], r, 1, part, s));   // dB_v
+        const OuterJobs oj{{xn, dqkv, xn, dqkv + 2 * d}, {g.kq, ldq, g.kq, ldq},
+                           {dqkv + 3 * d, xn + d, dqkv + 3 * d + 16, xn + d + 16}, {ldq, g.kq, ldq, g.kq},
+                           {G[0], G[1], G[2], G[3]}, {1, r, 1, r}, {d, 1, d, 1}};   // dA_q, dB_q, dA_v, dB_v
+        LSAM_TRY(launch_outer_reduce4<T>(oj, M, d, r, part, s));
         if (g.need_dx) {
             float* dxn = at<float>(ws, w.dxn);
             float* dxp = at<float>(ws, w.dxprev);

@@ -116,6 +116,12 @@ int launch_pack_tailblock(const float* wproj, const float* bproj, const float* g
 int launch_tailblock(const TailBlockArgs& a, hipStream_t s);
 
 size_t outer_reduce_ws(int M, int C);
+struct OuterJobs {   // four independent X^T Y token reductions with common M, C, R (one LoRA block's gradients)
+    const void* X[4]; int ldx[4];
+    const void* Y[4]; int ldy[4];
+    float* out[4]; long cs[4], ks[4];
+};
+template <typename T> int launch_outer_reduce4(const OuterJobs& j, int M, int C, int R, void* partial, hipStream_t s);   // partial: 4 x outer_reduce_ws
 template <typename T>
 int launch_outer_reduce(const T* X, int ldx, const T* Y, int ldy, int M, int C, int R, float* out,
                         long out_cs, long out_ks, void* partial, hipStream_t s);

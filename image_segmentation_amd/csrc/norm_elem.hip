@@ -396,6 +396,84 @@ int launch_outer_reduce(const T* X, int ldx, const T* Y, int ldy, int M, int C, 
     LSAM_LAUNCH_CHECK();
     return LSAM_OK;
 }
+// Four reductions of one LoRA block (dA_q, dB_q, dA_v, dB_v) in ONE partial + ONE final launch:
+// blockIdx.z selects the job.  Same arithmetic and summation order as four launch_outer_reduce calls
+// (bit-identical results); the point is four times the workgroups in flight for a latency-bound
+// kernel and two launches instead of eight.
+template <typename T>
+__global__ __launch_bounds__(64) void outer_partial4_kernel(const OuterJobs j, int M, int C, float* __restrict__ partial,
+                                                            size_t job_stride) {
+    __shared__ float ys[OR_MCH][16];
+    const int z = blockIdx.z;
+    const T* __restrict__ X = static_cast<const T*>(j.X[z]);
+    const T* __restrict__ Y = static_cast<const T*>(j.Y[z]);
+    const int ldx = j.ldx[z], ldy = j.ldy[z];
+    const int lane = threadIdx.x;
+    const int m0 = blockIdx.y * OR_MCH;
+    const int rows = min(OR_MCH, M - m0);
+    for (int i = lane; i < OR_MCH * 4; i += 64) {
+        const int r = i >> 2, q = i & 3;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (r < rows) v = load4(Y + (size_t)(m0 + r) * ldy + 4 * q);
+        *reinterpret_cast<f32x4*>(&ys[r][4 * q]) = v;
+    }
+    __syncthreads();
+    const int c = (blockIdx.x * 64 + lane) * 4;
+    if (c >= C) return;
+    f32x4 acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < rows; ++r) {
+        const f32x4 xv = load4(X + (size_t)(m0 + r) * ldx + c);
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            const f32x4 yv = *reinterpret_cast<const f32x4*>(&ys[r][4 * kq]);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[4 * kq + jj] += xv * yv[jj];
+        }
+    }
+    float* out = partial + z * job_stride + ((size_t)blockIdx.y * C + c) * 16;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            f32x4 o;
+            o[0] = acc[4 * kq + 0][jj]; o[1] = acc[4 * kq + 1][jj];
+            o[2] = acc[4 * kq + 2][jj]; o[3] = acc[4 * kq + 3][jj];
+            store4(out + jj * 16 + 4 * kq, o);
+        }
+    }
+}
+__global__ void outer_final4_kernel(const OuterJobs j, const float* __restrict__ partial, size_t job_stride, int nch, int C,
+                                    int R) {
+    const int z = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * R) return;
+    const int c = i / R, k = i % R;
+    const float* p = partial + z * job_stride;
+    float s = 0.f;
+    for (int ch = 0; ch < nch; ++ch) s += p[((size_t)ch * C + c) * 16 + k];
+    j.out[z][c * j.cs[z] + k * j.ks[z]] = s;
+}
+template <typename T> int launch_outer_reduce4(const OuterJobs& j, int M, int C, int R, void* partial, hipStream_t s) {
+    LSAM_REQUIRE(partial && M > 0 && C > 0, LSAM_ERR_BAD_ARG, "outer_reduce4: null/empty");
+    for (int z = 0; z < 4; ++z)
+        LSAM_REQUIRE(j.X[z] && j.Y[z] && j.out[z] && j.ldx[z] % 4 == 0 && j.ldy[z] % 4 == 0 && j.ldy[z] >= 16, LSAM_ERR_BAD_ARG,
+                     "outer_reduce4: job %d operands", z);
+    LSAM_REQUIRE(R >= 1 && R <= 16 && C % 4 == 0, LSAM_ERR_BAD_ARG, "outer_reduce4: need 1<=R<=16, C%%4==0");
+    const int nch = cdiv(M, OR_MCH);
+    const size_t job_stride = (size_t)nch * C * 16;
+    hipLaunchKernelGGL(outer_partial4_kernel<T>, dim3(cdiv(C, 256), nch, 4), dim3(64), 0, s, j, M, C,
+                       static_cast<float*>(partial), job_stride);
+    LSAM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(outer_final4_kernel, dim3(cdiv(C * R, 256), 4), dim3(256), 0, s, j, static_cast<const float*>(partial),
+                       job_stride, nch, C, R);
+    LSAM_LAUNCH_CHECK();
+    return LSAM_OK;
+}
+template int launch_outer_reduce4<float>(const OuterJobs&, int, int, int, void*, hipStream_t);
+template int launch_outer_reduce4<bf16>(const OuterJobs&, int, int, int, void*, hipStream_t);
+
 template int launch_outer_reduce<float>(const float*, int, const float*, int, int, int, int, float*, long, long, void*, hipStream_t);
 template int launch_outer_reduce<bf16>(const bf16*, int, const bf16*, int, int, int, int, float*, long, long, void*, hipStream_t);
 
