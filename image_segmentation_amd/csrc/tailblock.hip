@@ -34,6 +34,18 @@ namespace lsam {
 typedef __attribute__((address_space(3))) void* tail_lds_p;
 typedef __attribute__((address_space(3))) const char* tail_lds_cp;
 
+#ifndef TAIL_BS224
+#define TAIL_BS224 2
+#endif
+#ifndef TAIL_INTERLEAVE
+#define TAIL_INTERLEAVE 1
+#endif
+#ifndef TAIL_DMA_FRAC
+#define TAIL_DMA_FRAC 1
+#endif
+// number of leading fragment batches (of nb) that carry the chunk's DMA pieces
+constexpr int DMAB(int nb) { return nb / TAIL_DMA_FRAC > 0 ? nb / TAIL_DMA_FRAC : 1; }
+
 template <int B, int E, typename F> __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (B < E) {
         f(std::integral_constant<int, B>{});
@@ -165,8 +177,8 @@ __global__ __launch_bounds__(64 * NW, WPC) void tailblock_kernel(const TailBlock
     // ordered by hand: lds_wait() before the first use of a batch, scheduling barriers around the users.
     const unsigned lds0 = (unsigned)(size_t)(tail_lds_cp)(smem);
     const unsigned lds_lane = lds0 + (unsigned)lane * 16u;
-    constexpr int BS = 7;   // weight fragments per prefetch batch (28 VGPRs per register set)
-    static_assert(NTO % BS == 0 && I::W1F % BS == 0 && I::FR == I::W1F + I::W2F, "batching assumes 7 | NTO, 7 | 2 KS");
+    constexpr int BS = (MT == 1 && NTO == 28) ? 4 : (MT == 2 && NTO == 14) ? TAIL_BS224 : 7;   // weight fragments per prefetch batch (4 VGPRs each, two register sets)
+    static_assert(NTO % BS == 0 && I::W1F % BS == 0 && I::FR == I::W1F + I::W2F, "batching assumes BS | NTO, BS | 2 KS");
 
     const int ngroups = (M + TPG - 1) / TPG;
     int buf = 0;
@@ -211,7 +223,9 @@ __global__ __launch_bounds__(64 * NW, WPC) void tailblock_kernel(const TailBlock
                 constexpr int ks = 2 * pc + (b * BS) / NTO, ksc = ks < KS ? ks : KS - 1;
                 lds_wait();   // batch b is in registers
                 if constexpr (b + 1 < NBP && 2 * pc + ((b + 1) * BS) / NTO < KS) lds_frags<(b + 1) * BS, BS>(base, w[(b + 1) & 1]);
-                issue_part(b_, std::integral_constant<int, NBP>{}, pc + 1, buf ^ 1);   // pc + 1 <= NPC < nck
+                // all pieces go out in the first DMAB batches, so that the last of them has the rest of the
+                // chunk to land before the next barrier's vmcnt(0)
+                if constexpr (b < DMAB(NBP)) issue_part(b_, std::integral_constant<int, DMAB(NBP)>{}, pc + 1, buf ^ 1);   // pc + 1 <= NPC < nck
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (ks < KS) {   // KS may be odd: the last half chunk is empty
 #pragma unroll
@@ -299,7 +313,7 @@ __global__ __launch_bounds__(64 * NW, WPC) void tailblock_kernel(const TailBlock
                 constexpr int b = decltype(b_)::value;
                 lds_wait();   // batch b is in registers
                 if constexpr (b + 1 < NB) lds_frags<(b + 1) * BS, BS>(base, w[(b + 1) & 1]);
-                issue_part(b_, std::integral_constant<int, NB>{}, next_ck, buf ^ 1);
+                if constexpr (b < DMAB(NB)) issue_part(b_, std::integral_constant<int, DMAB(NB)>{}, next_ck, buf ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
                 // GELU work items: (mt, t, half) = 2 values each.  Row tile t = 0 is complete after the first
                 // half of the fc1 batches, t = 1 after all of them; the items are spread over the batches that
@@ -339,6 +353,19 @@ __global__ __launch_bounds__(64 * NW, WPC) void tailblock_kernel(const TailBlock
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) mma16(w[b & 1][i], hprev[mt], acc[mt][(b - NB1) * BS + i]);
                 }
+#if TAIL_INTERLEAVE
+                // issue order inside the batch: one MFMA, then the VALU instructions that fit in its shadow
+                // (an MFMA blocks vector issue for 8 of its 16 cycles).  Left alone, hipcc emits the GELU
+                // work as one block between MFMA runs and the matrix pipe idles meanwhile.
+                if constexpr (b >= H1) {
+                    constexpr int items = b < NB1 ? PB0 : PB1, per = (items * 24 + BS * MT - 1) / (BS * MT);
+#pragma unroll
+                    for (int i = 0; i < BS * MT; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, per, 0);   // VALU
+                    }
+                }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             });
 #pragma unroll
@@ -469,8 +496,16 @@ int launch_tailblock(const TailBlockArgs& a, hipStream_t s) {
                          (reinterpret_cast<uintptr_t>(a.xn_next) & 7) == 0,
                      LSAM_ERR_BAD_ARG, "tailblock: next-LayerNorm output needs gamma, beta and ldn %% 4 == 0");
     switch (tail_variant(a.d)) {
+#ifdef TAIL_224_MT2
+        case 0: return launch_tail<7, 14, 2, 4, 2>(a, s);
+#else
         case 0: return launch_tail<7, 14, 1, 8, 2>(a, s);    // 8 waves x 16 tokens: fits 2 waves per SIMD
+#endif
+#ifdef TAIL_448_MT1
+        case 1: return launch_tail<14, 28, 1, 8, 1>(a, s);
+#else
         case 1: return launch_tail<14, 28, 2, 4, 1>(a, s);   // 4 waves x 32 tokens: one wave per SIMD, 512 registers
+#endif
     }
     set_error("tailblock: width %d not supported", a.d);
     return LSAM_ERR_UNSUPPORTED;
