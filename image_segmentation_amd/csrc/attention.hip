@@ -516,6 +516,195 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnArgs p, con
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// v3 (bf16, windows with 65..208 keys: the 14x14 windows of Hiera stage 3 and the pooled 14x14 -> 7x7
+// transition).  The whole window's K and V ([224 rows][64 d] each, 56 KiB together) are staged ONCE by
+// LDS-DMA, so the softmax is a plain single pass (no running maximum, no rescaling of O) and there is
+// one barrier per workgroup.  Work is cut to what the window needs: 13 key tiles of 16 (not 4 x 64)
+// and ceil(nq / 16) query tiles (13 for a full window, not 16): 54 MFMAs per query tile.
+// One workgroup = one (window, head); its 4 waves take query tiles round-robin; two workgroups per CU
+// overlap one's staging with the other's MFMAs.
+// ---------------------------------------------------------------------------------------------
+template <int NKT>
+__global__ __launch_bounds__(256) void attnw_fwd_kernel(const AttnArgs p, const float c_log2) {
+    using T = bf16;
+    constexpr int U = (NKT + 1) / 2, NKP = 32 * U, RB = 128, TILE_B = NKP * RB, DT = 4;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* kb = smem;
+    char* vb = smem + TILE_B;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, lr = lane & 15;
+    const int H = p.H, W = p.W, nh = p.nh, hd = p.hd, dout = nh * hd;
+    const WinGeom G = make_geom(H, W, p.ws, p.pool);
+    // workgroup id -> (window, head) so that the heads of one window run back to back on ONE XCD
+    // (workgroups are dealt round-robin to the 8 XCDs): a head's 112-byte k/v slices share their
+    // 128-byte lines with the neighbouring heads', which then hit in that XCD's L2.
+    const int k_ = blockIdx.x >> 3;
+    const int h = k_ % nh, gwin = (k_ / nh) * 8 + (blockIdx.x & 7);
+    if (gwin >= p.N * G.nwy * G.nwx) return;   // uniform for the workgroup, before any barrier
+    const int win = gwin % (G.nwy * G.nwx), n = gwin / (G.nwy * G.nwx);
+    const int wy = win / G.nwx, wx = win % G.nwx;
+    const int rh = min(G.qh, G.Ho - wy * G.qh), rw = min(G.qw, G.Wo - wx * G.qw);
+    const int nq = rh * rw, nk = G.wsh * G.wsw;
+    const T* __restrict__ qkv = static_cast<const T*>(p.qkv);
+    const T* __restrict__ bias_t = static_cast<const T*>(p.bias_t);
+    const size_t img_tok = (size_t)n * H * W;
+
+    // ---- stage K and V: DMA instruction j covers tile rows 8j .. 8j+7 of K (j < NKP/8) or V --------
+    {
+        const int lrow = lane >> 3, dsrc = ((lane & 7) ^ lrow) * 8;   // swizzle applied on the source side
+        const bool dok = dsrc < hd;
+        constexpr int NI = NKP / 8;
+#pragma unroll 1
+        for (int j = wave; j < 2 * NI; j += 4) {
+            const int v = j >= NI ? 1 : 0, kk = 8 * (j - v * NI) + lrow;
+            const int ky = kk / G.wsw, kx = kk - ky * G.wsw;
+            const int y = wy * G.wsh + ky, x = wx * G.wsw + kx;
+            const void* src = &g_attn_zero16;
+            if (kk < nk && dok) {
+                const int part = (v ? 2 * dout : dout) + h * hd + dsrc;
+                src = (y < H && x < W) ? static_cast<const void*>(qkv + (img_tok + (size_t)y * W + x) * p.ldqkv + part)
+                                       : static_cast<const void*>(bias_t + part);
+            }
+            __builtin_amdgcn_global_load_lds((gbl_vp_t)src, (lds_vp_t)(smem + j * 1024), 16, 0, 0);
+        }
+    }
+    // ---- Q fragments of ALL of this wave's query tiles, requested while the K/V DMA is in flight --------
+    constexpr int MAXQT = (NKT + 3) / 4;   // query tiles per wave (nq <= nk <= 16 NKT)
+    bf16x8 qf_all[MAXQT][2];
+    int qtok_all[MAXQT];
+#pragma unroll
+    for (int i = 0; i < MAXQT; ++i) {
+        const int qi = (wave + 4 * i) * 16 + lr;
+        const bool qv = qi < nq;
+        const int iy = qv ? qi / rw : 0, ix = qv ? qi % rw : 0;
+        qtok_all[i] = qv ? (int)(((size_t)n * G.Ho + (wy * G.qh + iy)) * G.Wo + (wx * G.qw + ix)) : -1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int d0 = ks * 32 + g * 8;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            if (qv && d0 < hd) {
+                if (p.pool == 1) {
+                    const size_t tok = img_tok + (size_t)(wy * G.wsh + iy) * W + (wx * G.wsw + ix);
+                    load8f<T>(qkv + tok * p.ldqkv + h * hd + d0, v);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = -3.0e38f;
+                    for (int a = 0; a < p.pool; ++a)
+                        for (int b = 0; b < p.pool; ++b) {
+                            const int y = wy * G.wsh + iy * p.pool + a, x = wx * G.wsw + ix * p.pool + b;
+                            float t[8];
+                            if (y < H && x < W) load8f<T>(qkv + (img_tok + (size_t)y * W + x) * p.ldqkv + h * hd + d0, t);
+                            else load8f<T>(bias_t + h * hd + d0, t);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], t[j]);
+                        }
+                }
+            }
+            qf_all[i][ks] = frag_from_f<T>(v);
+        }
+    }
+    lds_dma_wait_barrier();
+
+    T* __restrict__ out = static_cast<T*>(p.out);
+    const int nqt = (nq + 15) >> 4;
+#pragma unroll
+    for (int i = 0; i < MAXQT; ++i) {
+        if (wave + 4 * i >= nqt) break;   // wave-uniform
+        const int qtok = qtok_all[i];
+        const bf16x8 (&qf)[2] = qf_all[i];
+        // ---- S^T = K . Q^T for all key tiles; lane = one query, 4 keys per tile --------------------
+        f32x4 s[NKT];
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+            const int row = t * 16 + lr;
+            const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kb + row * RB + (swz(row, g) << 4));
+            const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kb + row * RB + (swz(row, 4 + g) << 4));
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[1], s[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 4; t < NKT; ++t)   // keys past the window (alignment slots) never count; nk > 64
+            if (t * 16 + 16 > nk) {     // workgroup-uniform: only the window's last key tile(s) pay for the mask
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (t * 16 + g * 4 + r >= nk) s[t][r] = -1.0e30f;
+            }
+        float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+#pragma unroll
+        for (int t = 1; t < NKT; ++t) mx = fmaxf(fmaxf(mx, s[t][0]), fmaxf(fmaxf(s[t][1], s[t][2]), s[t][3]));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mneg = -mx * c_log2;
+        float l = 0.f;
+        bf16x8 pf[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float pv[8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float e = 0.f;
+                    if (2 * u + t < NKT) {
+                        e = __builtin_amdgcn_exp2f(fmaf(s[2 * u + t < NKT ? 2 * u + t : 0][r], c_log2, mneg));
+                        l += e;
+                    }
+                    pv[t * 4 + r] = e;
+                }
+            pf[u] = frag_from_f<T>(pv);
+        }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        // ---- O^T = V^T . P^T, V^T fragments by transposing LDS reads -------------------------------
+        f32x4 o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int row = 32 * u + 4 * g + (lr >> 2), ch = 2 * dt + ((lr & 3) >> 1);
+                const char* a0 = vb + row * RB + (swz(row, ch) << 4) + (lr & 1) * 8;
+                const int row1 = row + 16;
+                const char* a1 = vb + row1 * RB + (swz(row1, ch) << 4) + (lr & 1) * 8;
+                const s16x4_t x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(a0));
+                const s16x4_t x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(a1));
+                const uint2 u0 = __builtin_bit_cast(uint2, x0), u1 = __builtin_bit_cast(uint2, x1);
+                mma16(__builtin_bit_cast(bf16x8, make_uint4(u0.x, u0.y, u1.x, u1.y)), pf[u], o[dt]);
+            }
+        if (qtok >= 0) {
+            const float inv = 1.0f / l;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d0 = dt * 16 + g * 4;
+                if (d0 < hd) store4(out + (size_t)qtok * p.ldo + h * hd + d0, o[dt] * inv);
+            }
+            if (p.lse && g == 0) p.lse[(size_t)qtok * nh + h] = (mx * c_log2 + log2f(l)) * 0.69314718055994531f;
+        }
+    }
+}
+
+static int attnw_launch(const AttnArgs& a, hipStream_t s) {
+    constexpr int NKT = 13, LDSB = 2 * 32 * ((NKT + 1) / 2) * 128;
+    const WinGeom G = make_geom(a.H, a.W, a.ws, a.pool);
+    const float c = (1.0f / sqrtf((float)a.hd)) * 1.4426950408889634f;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        LSAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attnw_fwd_kernel<NKT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attnw_fwd_kernel<NKT>), dim3(8 * cdiv(a.N * G.nwy * G.nwx, 8) * a.nh), dim3(256), LDSB, s, a, c);
+    LSAM_LAUNCH_CHECK();
+    return LSAM_OK;
+}
+
 template <int QT> static int attn2_launch(const AttnArgs& a, int nqb, hipStream_t s) {
     const WinGeom G = make_geom(a.H, a.W, a.ws, a.pool);
     const float c = (1.0f / sqrtf((float)a.hd)) * 1.4426950408889634f;
@@ -559,6 +748,8 @@ template <typename T> int launch_attn_fwd(const AttnArgs& a, hipStream_t s) {
     const WinGeom G = make_geom(a.H, a.W, a.ws, a.pool);
     const int max_nq = G.qh * G.qw;
     if constexpr (sizeof(T) == 2) {
+        if (a.bias_t && a.hd <= 64 && a.ws > 0 && G.wsh * G.wsw > 64 && G.wsh * G.wsw <= 208 && max_nq > 64 && a.ldqkv % 8 == 0)
+            return attnw_launch(a, s);   // (pooled windows have few queries per staged K/V tile: the streaming kernel below)
         if (a.bias_t && a.hd <= 64 && G.wsh * G.wsw >= 128 && max_nq >= 32 && a.ldqkv % 8 == 0) {
             if (max_nq > 64) return attn2_launch<4>(a, cdiv(max_nq, 256), s);
             return attn2_launch<1>(a, 1, s);
