@@ -32,7 +32,7 @@ BPLUS = dict(embed_dim=112, num_heads=2)
 # dominant kernel of the step (rocprofv3 --kernel-trace --stats, profiles/): the fused block tail of the
 # sixteen 448-wide stage-3 blocks (tailblock.hip).  liblsam tags its live event records with 9000 + d.
 DOMINANT_CFG = 9448
-DOMINANT_KERNEL = ("lsam::tailblock_kernel<14, 28, 2, 4, 1> (proj + residual + LN2 + fc1 + GELU + fc2 + residual + "
+DOMINANT_KERNEL = ("lsam::tailpair_kernel<14, 28> (proj + residual + LN2 + fc1 + GELU + fc2 + residual + "
                    "next LN1, 448 wide; algorithmic FLOPs 18 M d^2 per launch)")
 
 

@@ -424,6 +424,393 @@ __global__ __launch_bounds__(64 * NW, WPC) void tailblock_kernel(const TailBlock
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last (unused) chunk prefetch must land before the LDS is released
 }
 
+// =====================================================================================================
+// Two waves per SIMD for the 448-wide tail: a PAIR of waves shares a 32-token tile.
+// The one-wave-per-SIMD kernel above cannot overlap anything: its MFMAs, the GELU VALU work, the DMA issue
+// and the LDS waits of a chunk simply add up (rocprof: matrix pipe busy ~36 %).  Here a workgroup has 8 waves
+// (two per SIMD, 256 registers each) and the two waves of a pair split the 32-token tile's state:
+//   wave hh keeps output channels [224 hh, 224 hh + 224): acc[2][NTO/2] (proj, fc2, residual) and, because a
+//   lane's accumulator channels ARE its k-slots (see above), the LayerNorm-2 output for the SAME channels,
+//   i.e. the K half hh of fc1's B operand.
+//   fc1 of a hidden chunk is therefore a K-split: each wave produces a partial 32-hidden x 32-token product
+//   over its 224 channels; the partials are exchanged through LDS as bf16 (2 KiB per wave and chunk, double
+//   buffered, riding on the chunk barrier), both waves add them in the same order, apply bias + GELU
+//   (redundantly: 16 values per lane) and so hold the identical fc2 B operand.
+//   fc2 is an N-split: wave hh accumulates its 224 output channels.
+// Pipeline per wave and iteration c (one barrier each): fc1 partial of chunk c | GELU of chunk c-1 from the
+// exchanged partials | fc2 of chunk c-2.  The three are independent, so with two waves per SIMD the hardware
+// overlaps one wave's VALU/LDS time with the other's MFMAs.
+#ifndef PAIR_BSP
+#define PAIR_BSP 4
+#endif
+#ifndef PAIR_BSM
+#define PAIR_BSM 4
+#endif
+template <int KS, int NTO> struct PairImg {
+    static_assert(KS % 2 == 0 && NTO == 2 * KS, "pair split needs an even number of k-steps");
+    static constexpr int KSH = KS / 2, NTH = NTO / 2;
+    static constexpr int NPC = KS / 2;              // proj chunks: two k-steps of all row tiles
+    static constexpr int FR = 2 * NTO;              // fragments per chunk; wave half hh owns [hh FR/2, (hh+1) FR/2)
+    static constexpr int HF = FR / 2;               //   proj: [kl][ntl]; MLP: fc1 [ksl][t] (2 KSH), then fc2 [ntl] (NTH)
+    static constexpr int B1_OFF = FR * 1024;        // fc1 biases of the chunk whose GELU runs in this iteration
+    static constexpr int CHUNK_B = (FR + 1) * 1024;
+    static constexpr int VEC = 16 * NTO;
+    static constexpr int XCH_OFF = 2 * CHUNK_B;     // exchange: [2 parities]{fc1 partials [8 waves][1 KiB], GELU halves [8 waves][1 KiB]}
+    static constexpr int STAT_OFF = XCH_OFF + 2 * 8 * 2048;   // LayerNorm statistics: [2][8 waves][32] floats
+    static constexpr int LDS_B = STAT_OFF + 2 * 8 * 32 * 4;
+};
+
+template <int KS, int NTO>
+__global__ void pack_tailpair_kernel(const float* __restrict__ wproj, const float* __restrict__ bproj,
+                                     const float* __restrict__ g2, const float* __restrict__ be2,
+                                     const float* __restrict__ w1, const float* __restrict__ b1,
+                                     const float* __restrict__ w2, const float* __restrict__ b2, int d, int nch,
+                                     char* __restrict__ img, float* __restrict__ vec) {
+    using I = PairImg<KS, NTO>;
+    const int hid = 4 * d, nck = I::NPC + nch + 2;
+    const long total = (long)nck * I::CHUNK_B / 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long byte = 2 * i;
+        const int ck = (int)(byte / I::CHUNK_B), in = (int)(byte % I::CHUNK_B);
+        if (in >= I::B1_OFF) continue;
+        const int f = in >> 10, lane = (in & 1023) >> 4, j = (in & 15) >> 1;
+        const int g = lane >> 4, lr = lane & 15;
+        const int hh = f / I::HF, fl = f % I::HF;
+        float v = 0.f;
+        if (ck < I::NPC) {
+            const int kl = fl / I::NTH, ntl = fl % I::NTH, ks = 2 * ck + kl;
+            const int row = 16 * (I::NTH * hh + ntl) + lr, k = 32 * ks + 8 * g + j;
+            v = wproj[(size_t)row * d + k];
+        } else {
+            const int c = ck - I::NPC;
+            const int perm = 16 * (j >> 2) + 4 * g + (j & 3);
+            if (fl < 2 * I::KSH) {   // fc1 of hidden chunk c, K half hh; row tile 0 of a half is the one it finalises
+                const int ksl = fl >> 1, t = (fl & 1) ^ hh, ks = I::KSH * hh + ksl;
+                const int hrow = 32 * c + 16 * t + lr, ch = 32 * ks + perm;
+                if (c < nch) v = w1[(size_t)hrow * d + ch];
+            } else {                 // fc2 of hidden chunk c - 2, output half hh; k-slots 0..3 = its own hidden tile
+                const int ntl = fl - 2 * I::KSH, row = 16 * (I::NTH * hh + ntl) + lr;
+                const int hcol = 32 * (c - 2) + 16 * ((j >> 2) ^ hh) + 4 * g + (j & 3);
+                if (c >= 2 && c - 2 < nch) v = w2[(size_t)row * hid + hcol];
+            }
+        }
+        reinterpret_cast<bf16*>(img)[i] = (bf16)v;
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nck * 256; i += gridDim.x * blockDim.x) {
+        const int ck = i / 256, e = i % 256, c = ck - I::NPC - 1;   // biases of the chunk GELU'd in iteration c + 1
+        const bool ok = c >= 0 && c < nch && e < 32;
+        reinterpret_cast<float*>(img + (size_t)ck * I::CHUNK_B + I::B1_OFF)[e] = ok ? b1[32 * c + e] : 0.f;
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 4 * I::VEC; i += gridDim.x * blockDim.x) {
+        const int which = i / I::VEC, e = i % I::VEC;
+        const float* src = which == 0 ? bproj : which == 1 ? g2 : which == 2 ? be2 : b2;
+        vec[i] = e < d ? src[e] : 0.f;
+    }
+}
+
+__device__ __forceinline__ void lds_write_b128(unsigned addr, const bf16x8& v) {
+    asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ bf16x8 lds_read_b128(unsigned addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+
+template <int KS, int NTO>
+__global__ __launch_bounds__(512) void tailpair_kernel(const TailBlockArgs p) {
+    using I = PairImg<KS, NTO>;
+    constexpr int KSH = I::KSH, NTH = I::NTH, HF = I::HF, MT = 2, NW = 8, CB = I::CHUNK_B, NF = CB / 1024;
+    constexpr int TPG = 16 * MT * (NW / 2), d = 16 * NTO;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pr = wave >> 1, hh = wave & 1;
+    const int g = lane >> 4, lr = lane & 15;
+    const int M = p.M, nch = p.nch;
+    const int nck = I::NPC + nch + 2;
+    constexpr float inv_d = 1.0f / (float)d;
+    const char* __restrict__ img = static_cast<const char*>(p.img);
+    const bf16* __restrict__ A = static_cast<const bf16*>(p.a);
+    const float* __restrict__ vproj = p.vec;
+    const float* __restrict__ vg2 = p.vec + I::VEC;
+    const float* __restrict__ vb2 = p.vec + 2 * I::VEC;
+    const float* __restrict__ vfc2 = p.vec + 3 * I::VEC;
+    const int cbase0 = 16 * NTH * hh + 4 * g;   // first of this lane's channels; tile ntl adds 16 ntl
+
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(img), 0, nck * CB, 0x00020000);
+    const unsigned dma_vo = (unsigned)(lane * 16 + wave * 1024);
+    auto issue_piece = [&](int ck, int buf, int i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (tail_lds_p)(smem + buf * CB + (wave + NW * i) * 1024), 16, dma_vo,
+                                                 ck * CB + NW * i * 1024, 0, 0);
+    };
+    auto issue_part = [&](auto b_, auto nbt_, int ck, int buf) {
+#if TAIL_ABL & 1
+        return;
+#endif
+        constexpr int b = decltype(b_)::value, NBT = decltype(nbt_)::value;
+        constexpr int NP = NF / NW, PPB = (NP + NBT - 1) / NBT;
+        if constexpr (NF % NW != 0 && b == 0) {   // the odd piece first: whatever is issued last is what the barrier waits for
+            if (wave + NW * NP < NF) issue_piece(ck, buf, NP);
+        }
+#pragma unroll
+        for (int i = b * PPB; i < (b + 1) * PPB && i < NP; ++i) issue_piece(ck, buf, i);
+    };
+    const unsigned lds0 = (unsigned)(size_t)(tail_lds_cp)(smem);
+    float* stat = reinterpret_cast<float*>(smem + I::STAT_OFF);
+    // LayerNorm statistics of the pair's 32 tokens: each wave reduces its 224 channels, the halves meet in LDS
+    auto pair_stats = [&](const f32x4 (&acc)[MT][NTH], float (&mean)[MT], float (&rstd)[MT]) {
+        float s[MT], q[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            s[mt] = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NTH; ++nt) s[mt] += (acc[mt][nt][0] + acc[mt][nt][1]) + (acc[mt][nt][2] + acc[mt][nt][3]);
+            s[mt] += __shfl_xor(s[mt], 16, 64);
+            s[mt] += __shfl_xor(s[mt], 32, 64);
+            if (g == 0) stat[wave * 32 + mt * 16 + lr] = s[mt];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            mean[mt] = (stat[(wave & ~1) * 32 + mt * 16 + lr] + stat[(wave | 1) * 32 + mt * 16 + lr]) * inv_d;
+            q[mt] = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NTH; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dd = acc[mt][nt][r] - mean[mt];
+                    q[mt] = fmaf(dd, dd, q[mt]);
+                }
+            q[mt] += __shfl_xor(q[mt], 16, 64);
+            q[mt] += __shfl_xor(q[mt], 32, 64);
+            if (g == 0) stat[NW * 32 + wave * 32 + mt * 16 + lr] = q[mt];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const float qq = stat[NW * 32 + (wave & ~1) * 32 + mt * 16 + lr] + stat[NW * 32 + (wave | 1) * 32 + mt * 16 + lr];
+            rstd[mt] = 1.0f / sqrtf(qq * inv_d + p.eps);
+        }
+    };
+
+    // the exchange area is read one iteration before its first real contents exist: it must hold finite numbers
+    for (int i = tid; i < 2 * 16384 / 16; i += 64 * NW)
+        *reinterpret_cast<f32x4*>(smem + I::XCH_OFF + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ngroups = (M + TPG - 1) / TPG;
+    int buf = 0;
+    if ((int)blockIdx.x < ngroups)
+        static_for<0, 4>([&](auto b_) { issue_part(b_, std::integral_constant<int, 4>{}, 0, 0); });
+#pragma unroll 1
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int m0 = grp * TPG + pr * (16 * MT);
+        int mrow[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) mrow[mt] = min(m0 + mt * 16 + lr, M - 1);
+
+        f32x4 acc[MT][NTH];
+        {   // ---- y = res + b + W_proj . a^T, this wave's 224 output channels over the full K ------------
+            // a fragments are fetched one chunk (two k-steps) ahead: holding all of them would push the asm-read
+            // weight fragments into scratch, and a register spilled between its ds_read and the wait is stale
+            const bf16* arow[MT];
+            bf16x8 afn[MT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                arow[mt] = A + (size_t)mrow[mt] * p.lda + 8 * g;
+#pragma unroll
+                for (int kl = 0; kl < 2; ++kl) afn[mt][kl] = *reinterpret_cast<const bf16x8*>(arow[mt] + 32 * kl);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTH; ++nt) {
+                const int c0 = cbase0 + 16 * nt;
+                const f32x4 bp = load4(vproj + c0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = load4(p.res + (size_t)mrow[mt] * d + c0) + bp;
+            }
+            static_for<0, I::NPC>([&](auto pc_) {
+                constexpr int pc = decltype(pc_)::value;
+                lds_dma_wait_barrier();
+                bf16x8 af[MT][2];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int kl = 0; kl < 2; ++kl) {
+                        af[mt][kl] = afn[mt][kl];
+                        if constexpr (pc + 1 < I::NPC)
+                            afn[mt][kl] = *reinterpret_cast<const bf16x8*>(arow[mt] + 32 * (2 * (pc + 1) + kl));
+                    }
+                unsigned ln;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+                const unsigned base = lds0 + buf * CB + hh * (HF * 1024) + ln * 16u;
+                constexpr int BS = PAIR_BSP, NBP = HF / BS;
+                static_assert(HF % BS == 0, "fragment batches");
+                bf16x8 w[2][BS];
+                lds_frags<0, BS>(base, w[0]);
+                static_for<0, NBP>([&](auto b_) {
+                    constexpr int b = decltype(b_)::value;
+                    lds_wait();
+                    if constexpr (b + 1 < NBP) lds_frags<(b + 1) * BS, BS>(base, w[(b + 1) & 1]);
+                    issue_part(b_, std::integral_constant<int, NBP>{}, pc + 1, buf ^ 1);   // pc + 1 <= NPC < nck
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < BS; ++i) {
+                        const int fl = b * BS + i, kl = fl / NTH, ntl = fl % NTH;
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) mma16(w[b & 1][i], af[mt][kl], acc[mt][ntl]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                buf ^= 1;
+            });
+        }
+        // ---- LayerNorm 2: this wave's channels become its K half of fc1's B operand ---------------------
+        bf16x8 xn[MT][KSH];
+        {
+            float mean[MT], rstd[MT];
+            pair_stats(acc, mean, rstd);
+#pragma unroll
+            for (int ksl = 0; ksl < KSH; ++ksl)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int nt = 2 * ksl + t, c0 = cbase0 + 16 * nt;
+                    const f32x4 gm = load4(vg2 + c0), bt = load4(vb2 + c0);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            xn[mt][ksl][4 * t + r] = (bf16)fmaf((acc[mt][nt][r] - mean[mt]) * rstd[mt], gm[r], bt[r]);
+                }
+        }
+        // ---- MLP ---------------------------------------------------------------------------------------
+        // iteration c: fc1 partials of chunk c | GELU of this wave's hidden tile of chunk c - 1 | fc2 of chunk c - 2
+        f32x4 own[MT];      // this wave's fp32 partial of the tile it finalises (chunk c - 1)
+        bf16x8 hown;        // its GELU output [mt][r] (chunk c - 2), the other half comes from the partner
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) own[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hown[j] = (bf16)0.f;
+#pragma unroll 1
+        for (int c = 0; c <= nch + 1; ++c) {
+            lds_wait();               // this wave's exchange writes of the previous iteration have reached LDS
+            lds_dma_wait_barrier();   // chunk landed, the partner's writes are visible, the other buffers are free
+            const int next_ck = I::NPC + c + 1 < nck ? I::NPC + c + 1 : 0;
+            unsigned ln;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+            const unsigned cbase = lds0 + buf * CB;
+            const unsigned base = cbase + hh * (HF * 1024) + ln * 16u;
+            const unsigned xw = lds0 + I::XCH_OFF + (c & 1) * 16384 + wave * 1024 + ln * 16u;               // mine, this iteration
+            const unsigned xr = lds0 + I::XCH_OFF + ((c & 1) ^ 1) * 16384 + (wave ^ 1) * 1024 + ln * 16u;   // partner's, previous
+            const unsigned baddr = cbase + I::B1_OFF + hh * 64 + (ln >> 4) * 16u;
+            constexpr int BS = PAIR_BSM;
+            static_assert(HF % BS == 0, "fragment batches");
+            constexpr int NB = HF / BS, F1 = 2 * KSH;   // fragments [0, F1): fc1, [F1, HF): fc2
+            constexpr int BG0 = 1, BGN = 4;             // GELU batches: 8 values over BGN batches
+            constexpr int BPW = (F1 + BS - 1) / BS;     // first batch after the last fc1 fragment
+            static_assert(BG0 + BGN < NB && BPW < NB && 8 % BGN == 0, "schedule");
+            bf16x8 w[2][BS];
+            f32x4 part[MT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) part[mt][0] = part[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bf16x8 pp, hq, hnew, hfull[MT];
+            f32x4 bi;
+            lds_frags<0, BS>(base, w[0]);
+            pp = lds_read_b128(xr);           // partner's partial of MY tile, chunk c - 1: [mt][r] bf16
+            bi = lds_f32x4(baddr);            // fc1 biases of my tile, chunk c - 1
+            hq = lds_read_b128(xr + 8192);    // partner's GELU half of chunk c - 2
+            static_for<0, NB>([&](auto b_) {
+                constexpr int b = decltype(b_)::value;
+                lds_wait();
+                if constexpr (b + 1 < NB) lds_frags<(b + 1) * BS, BS>(base, w[(b + 1) & 1]);
+                issue_part(b_, std::integral_constant<int, NB>{}, next_ck, buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (b == 0) {   // fc2 operand of chunk c - 2: own half in k-slots 0..3, the partner's in 4..7
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            hfull[mt][r] = hown[4 * mt + r];
+                            hfull[mt][4 + r] = hq[4 * mt + r];
+                        }
+                }
+                if constexpr (b >= BG0 && b < BG0 + BGN) {   // GELU of chunk c - 1, my tile
+#pragma unroll
+                    for (int e = (8 / BGN) * (b - BG0); e < (8 / BGN) * (b - BG0 + 1); ++e) {
+                        float x = (own[e >> 2][e & 3] + (float)pp[e]) + bi[e & 3];
+#if !(TAIL_ABL & 4)
+                        x = gelu_t<true>(x);
+#endif
+                        asm volatile("" : "+v"(x));
+                        hnew[e] = (bf16)x;
+                    }
+                }
+                if constexpr (b == BG0 + BGN) lds_write_b128(xw + 8192, hnew);
+                if constexpr (b == BPW) {   // fc1 partials of chunk c are complete: the partner's tile goes out as bf16
+                    bf16x8 pk;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pk[e] = (bf16)part[e >> 2][1][e & 3];
+                    lds_write_b128(xw, pk);
+                }
+#pragma unroll
+                for (int i = 0; i < BS; ++i) {
+                    const int fl = b * BS + i;
+                    if (fl < F1) {   // fc1 partial: fragment [ksl][tile], tile 0 = mine
+                        const int ksl = fl >> 1, t = fl & 1;
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) mma16(w[b & 1][i], xn[mt][ksl], part[mt][t]);
+                    } else {         // fc2 of chunk c - 2
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) mma16(w[b & 1][i], hfull[mt], acc[mt][fl - F1]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) own[mt] = part[mt][0];
+            hown = hnew;
+            buf ^= 1;
+        }
+        // ---- + fc2 bias, store; optional LayerNorm 1 of the next block -----------------------------------
+#pragma unroll
+        for (int nt = 0; nt < NTH; ++nt) {
+            const f32x4 b = load4(vfc2 + cbase0 + 16 * nt);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] += b;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + mt * 16 + lr;
+            if (m < M) {
+#pragma unroll
+                for (int nt = 0; nt < NTH; ++nt) store4(p.out + (size_t)m * d + cbase0 + 16 * nt, acc[mt][nt]);
+            }
+        }
+        if (p.xn_next) {   // kernel-uniform
+            bf16* __restrict__ xo = static_cast<bf16*>(p.xn_next);
+            float mean[MT], rstd[MT];
+            pair_stats(acc, mean, rstd);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = m0 + mt * 16 + lr;
+#pragma unroll
+                for (int nt = 0; nt < NTH; ++nt) {
+                    const int c0 = cbase0 + 16 * nt;
+                    const f32x4 gm = load4(p.gamma_n + c0), bt = load4(p.beta_n + c0);
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaf((acc[mt][nt][r] - mean[mt]) * rstd[mt], gm[r], bt[r]);
+                    if (m < M) store4(xo + (size_t)m * p.ldn + c0, v);
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+#ifndef TAIL_448_PAIR
+#define TAIL_448_PAIR 1
+#endif
+
 // supported widths: exactly 224 (KS 7) and 448 (KS 14), the Hiera-B+ stage-2 / stage-3 widths
 static int tail_variant(int d) {
     if (d == 224) return 0;
@@ -436,7 +823,11 @@ size_t tailblock_image_bytes(int d) {
     const int nch = tailblock_chunks(d);
     switch (tail_variant(d)) {
         case 0: return (size_t)(TailImg<7, 14>::NPC + nch + 1) * TailImg<7, 14>::CHUNK_B;
+#if TAIL_448_PAIR
+        case 1: return (size_t)(PairImg<14, 28>::NPC + nch + 2) * PairImg<14, 28>::CHUNK_B;
+#else
         case 1: return (size_t)(TailImg<14, 28>::NPC + nch + 1) * TailImg<14, 28>::CHUNK_B;
+#endif
     }
     return 0;
 }
@@ -460,8 +851,13 @@ int launch_pack_tailblock(const float* wproj, const float* bproj, const float* g
         hipLaunchKernelGGL((pack_tailblock_kernel<7, 14>), dim3(256), dim3(256), 0, s, wproj, bproj, g2, be2, w1, b1, w2,
                            b2, d, nch, im, vec);
     else
+#if TAIL_448_PAIR
+        hipLaunchKernelGGL((pack_tailpair_kernel<14, 28>), dim3(256), dim3(256), 0, s, wproj, bproj, g2, be2, w1, b1, w2,
+                           b2, d, nch, im, vec);
+#else
         hipLaunchKernelGGL((pack_tailblock_kernel<14, 28>), dim3(256), dim3(256), 0, s, wproj, bproj, g2, be2, w1, b1, w2,
                            b2, d, nch, im, vec);
+#endif
     LSAM_LAUNCH_CHECK();
     return LSAM_OK;
 }
@@ -485,6 +881,24 @@ template <int KS, int NTO, int MT, int NW, int WPC> static int launch_tail(const
     return LSAM_OK;
 }
 
+template <int KS, int NTO> static int launch_tailpair(const TailBlockArgs& a, hipStream_t s) {
+    using I = PairImg<KS, NTO>;
+    static_assert(I::LDS_B <= 160 * 1024, "LDS budget");
+    auto kern = tailpair_kernel<KS, NTO>;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        LSAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, I::LDS_B));
+        attr_set = true;
+    }
+    const int ngroups = cdiv(a.M, 128);
+    const int grid = ngroups < 256 ? ngroups : 256;   // persistent, one 8-wave workgroup per CU
+    const int rec = prof_begin(s);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), I::LDS_B, s, a);
+    LSAM_LAUNCH_CHECK();
+    prof_end(rec, s, 18.0 * a.M * a.d * a.d, 9000 + a.d, a.M, a.d, a.d);
+    return LSAM_OK;
+}
+
 int launch_tailblock(const TailBlockArgs& a, hipStream_t s) {
     LSAM_REQUIRE(a.a && a.res && a.out && a.img && a.vec, LSAM_ERR_BAD_ARG, "tailblock: null argument");
     LSAM_REQUIRE(a.M > 0 && a.nch == tailblock_chunks(a.d) && a.lda >= a.d && a.lda % 8 == 0, LSAM_ERR_BAD_ARG,
@@ -501,7 +915,9 @@ int launch_tailblock(const TailBlockArgs& a, hipStream_t s) {
 #else
         case 0: return launch_tail<7, 14, 1, 8, 2>(a, s);    // 8 waves x 16 tokens: fits 2 waves per SIMD
 #endif
-#ifdef TAIL_448_MT1
+#if TAIL_448_PAIR
+        case 1: return launch_tailpair<14, 28>(a, s);        // 8 waves, wave pairs share 32 tokens: two waves per SIMD
+#elif defined(TAIL_448_MT1)
         case 1: return launch_tail<14, 28, 1, 8, 1>(a, s);
 #else
         case 1: return launch_tail<14, 28, 2, 4, 1>(a, s);   // 4 waves x 32 tokens: one wave per SIMD, 512 registers

@@ -16,7 +16,8 @@ def timeit(fn, R=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / R
 print(os.environ.get("LSAM_LIB", "liblsam.so"))
-for d, M in [(112, 16 * 256 * 256), (224, 16 * 128 * 128)]:
+ONLY_TAIL = bool(os.environ.get("FB_TAIL"))
+for d, M in ([] if ONLY_TAIL else [(112, 16 * 256 * 256), (224, 16 * 128 * 128)]):
     x = torch.randn(M, d, device=dev)
     g, b = torch.ones(d, device=dev), torch.zeros(d, device=dev)
     img, bias = ops.mlp_block_pack(torch.randn(4 * d, d, device=dev) / math.sqrt(d), torch.randn(4 * d, device=dev),
@@ -24,7 +25,7 @@ for d, M in [(112, 16 * 256 * 256), (224, 16 * 128 * 128)]:
     y = torch.empty_like(x)
     us = timeit(lambda: ops.mlp_block_fwd(x, g, b, img, bias, out=y))
     print(f"mlp_block d={d} M={M}: {us:8.1f} us  {16.0*M*d*d/us/1e6:7.1f} TF/s  {M*d*8/us/1e6:5.2f} TB/s")
-for nh, H in [(2, 256)]:
+for nh, H in ([] if ONLY_TAIL else [(2, 256)]):
     d = nh * 56
     x = torch.randn(16, H, H, d, device=dev)
     g, b = torch.ones(d, device=dev), torch.zeros(d, device=dev)
