@@ -54,7 +54,7 @@ def lib() -> C.CDLL:
         for name in ("lsam_hiera_arena_bytes", "lsam_hiera_workspace_bytes", "lsam_outer_reduce_ws",
                      "lsam_window_block_image_bytes", "lsam_window_block_bias_floats",
                      "lsam_mlp_block_image_bytes", "lsam_mlp_block_bias_floats",
-                     "lsam_tail_block_image_bytes", "lsam_tail_block_vec_floats"):
+                     "lsam_tail_block_image_bytes", "lsam_tail_block_vec_floats", "lsam_patch_embed_image_bytes"):
             getattr(L, name).restype = C.c_size_t
         L.lsam_hiera_arena_bytes.argtypes = [C.c_void_p]
         L.lsam_hiera_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -88,8 +88,10 @@ def lib() -> C.CDLL:
         L.lsam_outer_reduce.argtypes = [i, vp, i, vp, i, i, i, i, vp, l, l, vp, vp]
         for name in ("lsam_window_block_image_bytes", "lsam_window_block_bias_floats",
                      "lsam_mlp_block_image_bytes", "lsam_mlp_block_bias_floats",
-                     "lsam_tail_block_image_bytes", "lsam_tail_block_vec_floats"):
+                     "lsam_tail_block_image_bytes", "lsam_tail_block_vec_floats", "lsam_patch_embed_image_bytes"):
             getattr(L, name).argtypes = [i]
+        L.lsam_patch_embed_pack.argtypes = [vp, i, vp, vp]
+        L.lsam_patch_embed_fwd.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp]
         L.lsam_tail_block_pack.argtypes = [vp] * 8 + [i, vp, vp, vp]
         L.lsam_tail_block_fwd.argtypes = [vp, i, vp, vp, vp, vp, vp, i, vp, vp, i, i, f, vp]
         L.lsam_window_block_pack.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp]
@@ -133,5 +135,5 @@ EXPORTED = [
     "lsam_window_block_image_bytes", "lsam_window_block_bias_floats", "lsam_window_block_pack",
     "lsam_window_block_fwd", "lsam_mlp_block_image_bytes", "lsam_mlp_block_bias_floats", "lsam_mlp_block_pack",
     "lsam_mlp_block_fwd", "lsam_tail_block_image_bytes", "lsam_tail_block_vec_floats", "lsam_tail_block_pack",
-    "lsam_tail_block_fwd",
+    "lsam_tail_block_fwd", "lsam_patch_embed_image_bytes", "lsam_patch_embed_pack", "lsam_patch_embed_fwd",
 ]

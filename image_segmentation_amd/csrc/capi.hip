@@ -95,6 +95,17 @@ int lsam_im2col_patch(int dtype, const float* img, void* cols, int ldc, int N, i
              launch_im2col_patch<bf16>(img, static_cast<bf16*>(cols), ldc, N, S, s));
 }
 
+size_t lsam_patch_embed_image_bytes(int embed_dim) { return patch_embed_supported(embed_dim) ? patch_embed_image_bytes(embed_dim) : 0; }
+int lsam_patch_embed_pack(const float* proj_w, int embed_dim, void* image, lsam_stream_t stream) {
+    LSAM_REQUIRE(patch_embed_supported(embed_dim), LSAM_ERR_UNSUPPORTED, "patch_embed: embed_dim %d not supported", embed_dim);
+    return launch_pack_patch_embed(proj_w, embed_dim, image, static_cast<hipStream_t>(stream));
+}
+int lsam_patch_embed_fwd(const float* frames, const void* image, const float* proj_b, const float* pos, float* out, int N,
+                         int S, int embed_dim, lsam_stream_t stream) {
+    LSAM_REQUIRE(patch_embed_supported(embed_dim), LSAM_ERR_UNSUPPORTED, "patch_embed: embed_dim %d not supported", embed_dim);
+    return launch_patch_embed(frames, image, proj_b, pos, out, N, S, embed_dim, static_cast<hipStream_t>(stream));
+}
+
 size_t lsam_window_block_image_bytes(int nh) { return (nh == 1 || nh == 2) ? winblock_image_bytes(nh) : 0; }
 size_t lsam_window_block_bias_floats(int nh) { return (nh == 1 || nh == 2) ? winblock_bias_floats(nh) : 0; }
 int lsam_window_block_pack(const float* qkv_w, const float* qkv_b, const float* proj_w, const float* proj_b, int nh,

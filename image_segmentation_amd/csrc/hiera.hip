@@ -53,6 +53,8 @@ struct lsam_hiera {
     int stage_ch[4], stage_grid[4];
     int grid0;
     size_t wpatch, bpatch, pos;
+    size_t wpatch_img;   // bf16: fragment-order weight image of the direct PatchEmbed kernel (patchembed.hip)
+    bool direct_patch;
     size_t arena_bytes;
     size_t esz;
     int first_lora;
@@ -83,7 +85,7 @@ static FwdWs plan_ws(const lsam_hiera* h, int N, bool with_grad) {
     Bump b;
     const size_t e = h->esz;
     const size_t M0 = (size_t)N * h->grid0 * h->grid0;
-    w.im2col = b.take(M0 * PATCH_K * e);
+    w.im2col = b.take(h->direct_patch ? 0 : M0 * PATCH_K * e);
     size_t xn = 0, qkv = 0, sc = 0, a = 0, hb = 0;
     for (const BlockGeom& g : h->blk) {
         const size_t Mi = (size_t)N * g.gin * g.gin, Mo = (size_t)N * g.gout * g.gout;
@@ -177,6 +179,7 @@ static int pack_t(lsam_hiera* h, const lsam_block_params_t* bp, const float* pat
                   const float* pos, void* arena, hipStream_t s) {
     const int e0 = h->cfg.embed_dim;
     LSAM_TRY(launch_pack_matrix<T>(patch_w, 147, 1, e0, 147, at<T>(arena, h->wpatch), PATCH_K, s));
+    if (h->direct_patch) LSAM_TRY(launch_pack_patch_embed(patch_w, e0, at<char>(arena, h->wpatch_img), s));
     LSAM_TRY(launch_pack_matrix<float>(patch_b, 0, 1, 1, e0, at<float>(arena, h->bpatch), e0, s));
     LSAM_TRY(launch_pack_matrix<float>(pos, 0, 1, 1, h->grid0 * h->grid0 * e0, at<float>(arena, h->pos),
                                        h->grid0 * h->grid0 * e0, s));
@@ -257,11 +260,17 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
                      const FwdWs& w, bool with_grad, hipStream_t s) {
     const int e0 = h->cfg.embed_dim, g0 = h->grid0;
     const int M0 = N * g0 * g0;
-    // PatchEmbed (backbones/utils.py:85-93) + pos embed (hieradet.py:307-312) as im2col + fused GEMM
-    LSAM_TRY(launch_im2col_patch<T>(img, at<T>(ws, w.im2col), PATCH_K, N, h->cfg.img_size, s));
-    LSAM_TRY(linear<T>(at<T>(ws, w.im2col), PATCH_K, at<T>(arena, h->wpatch), PATCH_K, at<float>(arena, h->bpatch),
-                       at<float>(arena, h->pos), e0, g0 * g0, nullptr, 0, stage_out[0], e0, nullptr, 0,
-                       LSAM_EPI_OUT_F32, M0, e0, PATCH_K, s));
+    // PatchEmbed (backbones/utils.py:85-93) + pos embed (hieradet.py:307-312): bf16 as one direct convolution
+    // kernel, fp32 as im2col + fused GEMM
+    if (h->direct_patch) {
+        LSAM_TRY(launch_patch_embed(img, at<char>(arena, h->wpatch_img), at<float>(arena, h->bpatch), at<float>(arena, h->pos),
+                                    stage_out[0], N, h->cfg.img_size, e0, s));
+    } else {
+        LSAM_TRY(launch_im2col_patch<T>(img, at<T>(ws, w.im2col), PATCH_K, N, h->cfg.img_size, s));
+        LSAM_TRY(linear<T>(at<T>(ws, w.im2col), PATCH_K, at<T>(arena, h->wpatch), PATCH_K, at<float>(arena, h->bpatch),
+                           at<float>(arena, h->pos), e0, g0 * g0, nullptr, 0, stage_out[0], e0, nullptr, 0,
+                           LSAM_EPI_OUT_F32, M0, e0, PATCH_K, s));
+    }
     float* x = stage_out[0];
     bool xn_ready = false;   // the previous block's fused tail already wrote this block's LN1 output
     for (size_t i = 0; i < h->blk.size(); ++i) {
@@ -511,6 +520,8 @@ int lsam_hiera_create(const lsam_hiera_config_t* c, lsam_hiera_t** out) {
     Bump b;
     const size_t e = h->esz;
     h->wpatch = b.take((size_t)c->embed_dim * PATCH_K * e);
+    h->direct_patch = c->dtype == LSAM_BF16 && patch_embed_supported(c->embed_dim);
+    h->wpatch_img = h->direct_patch ? b.take(patch_embed_image_bytes(c->embed_dim)) : 0;
     h->bpatch = b.take((size_t)c->embed_dim * 4);
     h->pos = b.take((size_t)h->grid0 * h->grid0 * c->embed_dim * 4);
     for (int i = 0; i < depth; ++i) {

@@ -59,6 +59,13 @@ int launch_cast(const float* src, int lds, T* dst, int ldd, int rows, int cols, 
 template <typename T>
 int launch_im2col_patch(const float* img, T* cols, int ldc, int N, int S, hipStream_t s);
 
+// direct PatchEmbed convolution + bias + position embedding (patchembed.hip), bf16 MFMA, fp32 out
+bool patch_embed_supported(int e0);
+size_t patch_embed_image_bytes(int e0);
+int launch_pack_patch_embed(const float* w, int e0, void* img, hipStream_t s);
+int launch_patch_embed(const float* frames, const void* wimg, const float* bias, const float* pos, float* out, int N, int S,
+                       int e0, hipStream_t s);
+
 // fused attention half of a same-dim 8x8-window block (winblock.hip)
 struct WinBlockArgs {
     const float* x;       // [N*H*W][D] fp32 residual stream (D = nh * hd)

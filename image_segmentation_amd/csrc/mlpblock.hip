@@ -11,6 +11,8 @@
 // The weight chunks (W1 rows + W2 columns + the chunk's fc1 biases, 30-60 KiB) are packed once into the exact LDS image and
 // streamed global -> LDS by LDS-DMA, double-buffered: all waves of the workgroup walk the chunks in
 // lock-step (one barrier per chunk) and the DMA of chunk c+1 lands while chunk c is multiplied.
+#include <type_traits>
+
 #include "kernels.hpp"
 
 namespace lsam {
@@ -20,6 +22,25 @@ namespace lsam {
 #endif
 typedef __attribute__((address_space(3))) void* mlp_lds_p;
 typedef const __attribute__((address_space(1))) void* mlp_gbl_p;
+typedef __attribute__((address_space(3))) const char* mlp_lds_cp;
+
+namespace {
+template <int B, int E, typename F> __device__ __forceinline__ void mlp_static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        mlp_static_for<B + 1, E>(f);
+    }
+}
+// LDS reads the compiler cannot see (it waits vmcnt(0), i.e. for the chunk DMA just issued, in front of every
+// LDS read it can see after an LDS-DMA); ordered by hand with mlp_lds_wait() and scheduling barriers.
+template <int OFF> __device__ __forceinline__ void mlp_rd(unsigned addr, bf16x8& dst) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int OFF> __device__ __forceinline__ void mlp_rd(unsigned addr, f32x4& dst) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void mlp_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+}  // namespace
 
 template <int KS, int NTO> struct MlpImg {
     static constexpr int NSUB = (KS + 1) / 2;                  // [64][64] sub-tiles of a W1 chunk
@@ -49,7 +70,9 @@ __global__ void pack_mlpblock_kernel(const float* __restrict__ w1, const float* 
             continue;
         } else if (in < I::W1_B) {
             const int kk = in / 8192, r8 = in % 8192;
-            const int row = r8 / 128, chunk = ((r8 % 128) >> 4) ^ (row & 7), k = 64 * kk + 8 * chunk + ((r8 & 15) >> 1);
+            // K order of fc1 = the accumulator layout of the residual tile (see the kernel): k-slot s of a
+            // 64-wide sub-tile holds channel mlp_slot_to_ch(s)
+            const int row = r8 / 128, chunk = ((r8 % 128) >> 4) ^ (row & 7), k = 64 * kk + mlp_slot_to_ch(8 * chunk + ((r8 & 15) >> 1));
             const int hrow = c * 64 + row;
             if (hrow < hid && k < d) v = w1[(size_t)hrow * d + k];
         } else {
@@ -106,39 +129,36 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlpblock_kernel(cons
 #pragma unroll 1
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int m0 = grp * TPG + wave * TPW;
-        // ---- LayerNorm 2 into operand fragments (rows past M are clamped and never stored) -----------
+        // ---- x is read ONCE, in accumulator layout (lane: token lr, channels 16 nt + 4 g + r): it seeds the
+        // fc2 accumulators (the residual never leaves them) and LayerNorm 2 is taken from the same registers.
+        // A lane's accumulator channels are the 8 k-slots 8g..8g+7 of k-step ks if slot 8g + 4t + r means
+        // channel 32 ks + 16 t + 4 g + r: fc1's K order is packed that way, so no transpose is needed.
+        // Rows past M are clamped and never stored.
         bf16x8 xn[MT][KS];
+        f32x4 acc2[MT][NTO];
         {
-            float xr[MT][KS][8], sum[MT];
+            float mean[MT], rstd[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int m = min(m0 + mt * 16 + lr, M - 1);
                 const float* row = p.x + (size_t)m * d;
-                sum[mt] = 0.f;
+                float s = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const int c0 = 32 * ks + 8 * g;
-                    f32x4 a = zero4, b = zero4;
-                    if (c0 < d) { a = load4(row + c0); b = load4(row + c0 + 4); }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { xr[mt][ks][j] = a[j]; xr[mt][ks][4 + j] = b[j]; }
-                    sum[mt] += ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]));
+                for (int nt = 0; nt < NTO; ++nt) {
+                    const int c0 = 16 * nt + 4 * g;
+                    acc2[mt][nt] = c0 < d ? load4(row + c0) : zero4;
+                    s += (acc2[mt][nt][0] + acc2[mt][nt][1]) + (acc2[mt][nt][2] + acc2[mt][nt][3]);
                 }
-            }
-            float mean[MT], rstd[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                float s = sum[mt];
                 s += __shfl_xor(s, 16, 64);
                 s += __shfl_xor(s, 32, 64);
                 mean[mt] = s / (float)d;
                 float q = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-                    if (32 * ks + 8 * g < d) {
+                for (int nt = 0; nt < NTO; ++nt)
+                    if (16 * nt + 4 * g < d) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const float dd = xr[mt][ks][j] - mean[mt];
+                        for (int r = 0; r < 4; ++r) {
+                            const float dd = acc2[mt][nt][r] - mean[mt];
                             q += dd * dd;
                         }
                     }
@@ -147,40 +167,102 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlpblock_kernel(cons
                 rstd[mt] = 1.0f / sqrtf(q / (float)d + p.eps);
             }
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int c0 = 32 * ks + 8 * g;
-                const bool ok = c0 < d;
-                f32x4 g0 = zero4, g1 = zero4, b0 = zero4, b1 = zero4;
-                if (ok) {
-                    g0 = load4(p.gamma + c0); g1 = load4(p.gamma + c0 + 4);
-                    b0 = load4(p.beta + c0);  b1 = load4(p.beta + c0 + 4);
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int nt = 2 * ks + t, c0 = 16 * nt + 4 * g;
+                    const bool ok = nt < NTO && c0 < d;
+                    f32x4 gm = zero4, bt = zero4;
+                    if (ok) { gm = load4(p.gamma + c0); bt = load4(p.beta + c0); }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            xn[mt][ks][4 * t + r] = (bf16)(ok ? (acc2[mt][nt < NTO ? nt : 0][r] - mean[mt]) * rstd[mt] * gm[r] + bt[r] : 0.f);
                 }
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    bf16x8 f;
+            for (int nt = 0; nt < NTO; ++nt) {   // + fc2 bias
+                const int c0 = 16 * nt + 4 * g;
+                if (c0 < d) {
+                    const f32x4 b = load4(b2p + c0);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        f[j] = (bf16)(ok ? (xr[mt][ks][j] - mean[mt]) * rstd[mt] * g0[j] + b0[j] : 0.f);
-                        f[4 + j] = (bf16)(ok ? (xr[mt][ks][4 + j] - mean[mt]) * rstd[mt] * g1[j] + b1[j] : 0.f);
-                    }
-                    xn[mt][ks] = f;
+                    for (int mt = 0; mt < MT; ++mt) acc2[mt][nt] += b;
                 }
             }
         }
-        f32x4 acc2[MT][NTO];
-#pragma unroll
-        for (int nt = 0; nt < NTO; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc2[mt][nt] = zero4;
 
 #pragma unroll 1
         for (int c = 0; c < nch; ++c) {
             lds_dma_wait_barrier();   // chunk c landed; every wave is done with the other buffer
-            {
-                // next chunk in stream order (wraps to chunk 0 of the next token group)
-                const bool more = c + 1 < nch || grp + (int)gridDim.x < ngroups;
-                if (more) issue(c + 1 < nch ? c + 1 : 0, buf ^ 1);
+            // next chunk in stream order (wraps to chunk 0 of the next token group)
+            const bool more = c + 1 < nch || grp + (int)gridDim.x < ngroups;
+            const int next_c = c + 1 < nch ? c + 1 : 0;
+            if constexpr (KS == 4 && NTO == 7) {
+                // the 112-wide stage: hand-ordered LDS reads, so that the DMA of the next chunk really
+                // runs under this chunk's MFMAs and GELU.  Fragment (row tile nt, 16-byte column c) sits at
+                // row * 128 + ((c ^ (row & 7)) << 4), row = 16 nt + lr: two per-lane bases (c = g, c = 4 + g)
+                // plus immediates.
+                const unsigned cb = (unsigned)(size_t)(mlp_lds_cp)(smem) + buf * CB;
+                const unsigned sw0 = lr * 128 + ((g ^ (lr & 7)) << 4), sw1 = lr * 128 + (((4 + g) ^ (lr & 7)) << 4);
+                const unsigned a0 = cb + sw0, a1 = cb + sw1, ab = cb + I::B1_OFF + g * 16;
+                bf16x8 wa[8], wb[8], w2f[2 * NTO];
+                f32x4 acc1[MT][4];
+                mlp_static_for<0, 4>([&](auto nt_) { mlp_rd<decltype(nt_)::value * 64>(ab, acc1[0][decltype(nt_)::value]); });
+                mlp_static_for<0, 8>([&](auto i_) {   // k-steps 0, 1
+                    constexpr int i = decltype(i_)::value, ks = i >> 2, nt = i & 3;
+                    mlp_rd<(ks >> 1) * 8192 + nt * 2048>((ks & 1) ? a1 : a0, wa[i]);
+                });
+                if (more) issue(next_c, buf ^ 1);
+                mlp_lds_wait();
+                mlp_static_for<0, 8>([&](auto i_) {   // k-steps 2, 3
+                    constexpr int i = decltype(i_)::value, ks = 2 + (i >> 2), nt = i & 3;
+                    mlp_rd<(ks >> 1) * 8192 + nt * 2048>((ks & 1) ? a1 : a0, wb[i]);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int mt = 1; mt < MT; ++mt) acc1[mt][nt] = acc1[0][nt];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) mma16(wa[i], xn[mt][i >> 2], acc1[mt][i & 3]);
+                __builtin_amdgcn_sched_barrier(0);
+                mlp_lds_wait();
+                mlp_static_for<0, 2 * NTO>([&](auto i_) {   // all fc2 fragments of the chunk: they land under the GELU
+                    constexpr int i = decltype(i_)::value, k2 = i / NTO, nt = i % NTO;
+                    mlp_rd<I::W1_B + nt * 2048>(k2 ? a1 : a0, w2f[i]);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) mma16(wb[i], xn[mt][2 + (i >> 2)], acc1[mt][i & 3]);
+                bf16x8 hf[MT][2];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+#if MLP_ABL & 4
+                                hf[mt][k2][4 * t + r] = (bf16)(acc1[mt][2 * k2 + t][r]);
+#else
+                                hf[mt][k2][4 * t + r] = (bf16)gelu_t<true>(acc1[mt][2 * k2 + t][r]);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                mlp_lds_wait();
+#pragma unroll
+                for (int i = 0; i < 2 * NTO; ++i)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) mma16(w2f[i], hf[mt][i / NTO], acc2[mt][i % NTO]);
+                __builtin_amdgcn_sched_barrier(0);
+                buf ^= 1;
+                continue;
             }
+            if (more) issue(next_c, buf ^ 1);
 #if MLP_ABL & 2
             buf ^= 1;
             continue;
@@ -231,22 +313,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlpblock_kernel(cons
                 }
             buf ^= 1;
         }
-        // ---- fc2 bias + residual + store: one row block's operands are requested together -------------
+        // ---- store: the accumulators already hold x + b2 + fc2(...) ------------------------------------------
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int m = m0 + mt * 16 + lr;
-            const float* xrow = p.x + (size_t)min(m, M - 1) * d;
-            f32x4 r[NTO];
-#pragma unroll
-            for (int nt = 0; nt < NTO; ++nt) {
-                const int c0 = min(16 * nt + 4 * g, d - 4);
-                r[nt] = load4(xrow + c0) + load4(b2p + c0);
-            }
             if (m < M) {
 #pragma unroll
                 for (int nt = 0; nt < NTO; ++nt) {
                     const int c0 = 16 * nt + 4 * g;
-                    if (c0 < d) store4(p.y + (size_t)m * d + c0, acc2[mt][nt] + r[nt]);
+                    if (c0 < d) store4(p.y + (size_t)m * d + c0, acc2[mt][nt]);
                 }
             }
         }

@@ -223,6 +223,35 @@ def mlp_block_fwd(x, norm2_w, norm2_b, img, bias, eps: float = 1e-6, out=None):
     return y
 
 
+def patch_embed_pack(proj_w):
+    """PatchEmbed proj.weight [E,3,7,7] fp32 -> fragment-order bf16 weight image of the direct convolution."""
+    _need_gpu(proj_w)
+    e0 = proj_w.shape[0]
+    nbytes = lib().lsam_patch_embed_image_bytes(e0)
+    if nbytes == 0:
+        raise _C.LsamError(f"direct patch embed: embed_dim {e0} not supported")
+    img = torch.empty(nbytes, dtype=torch.uint8, device=proj_w.device)
+    w = proj_w.detach().float().contiguous()
+    check(lib().lsam_patch_embed_pack(ptr(w), e0, ptr(img), stream()))
+    return img
+
+
+def patch_embed_fwd(frames, img, proj_b, pos):
+    """frames fp32 [N,3,S,S] -> fp32 [N, S/4, S/4, E] = conv7x7/4 (bf16 MFMA) + bias + pos (see lsam_patch_embed_fwd)."""
+    _need_gpu(frames, img, proj_b, pos)
+    assert frames.dtype == torch.float32 and frames.is_contiguous() and frames.shape[1] == 3
+    N, _, S, S2 = frames.shape
+    assert S == S2 and S % 4 == 0
+    e0 = proj_b.numel()
+    G = S // 4
+    pos = pos.detach().float().contiguous()
+    assert pos.numel() == G * G * e0
+    b = proj_b.detach().float().contiguous()
+    out = torch.empty(N, G, G, e0, dtype=torch.float32, device=frames.device)
+    check(lib().lsam_patch_embed_fwd(ptr(frames), ptr(img), ptr(b), ptr(pos), ptr(out), N, S, e0, stream()))
+    return out
+
+
 def tail_block_pack(proj_w, proj_b, norm2_w, norm2_b, fc1_w, fc1_b, fc2_w, fc2_b):
     """fp32 module parameters -> (streamed weight image uint8, packed fp32 vectors) of the fused block tail."""
     params = (proj_w, proj_b, norm2_w, norm2_b, fc1_w, fc1_b, fc2_w, fc2_b)

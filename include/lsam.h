@@ -129,6 +129,17 @@ int lsam_cast(int dtype, const float* src, int lds, void* dst, int ldd, int rows
 int lsam_im2col_patch(int dtype, const float* img, void* cols, int ldc, int N, int S,
                       lsam_stream_t stream);
 
+/* PatchEmbed + position embedding in one kernel (bf16 MFMA, fp32 out), no column matrix in memory:
+ *   out[n][oy][ox][:] = Conv2d(3, E, kernel 7, stride 4, padding 3)(frames)[n, :, oy, ox] + proj_b + pos[oy][ox][:]
+ * (PatchEmbed.forward, backbones/utils.py:85-93, incl. its NCHW -> NHWC permute, and the `x = x + self._get_pos_embed(...)`
+ * of Hiera.forward, hieradet.py:307-312; pos is that embedding, fp32 [(S/4)^2][E]).
+ * frames fp32 [N,3,S,S], S % 4 == 0; E % 16 == 0, E <= 144 (0 bytes / LSAM_ERR_UNSUPPORTED otherwise).
+ * lsam_patch_embed_pack builds the weight image (lsam_patch_embed_image_bytes bytes) from proj.weight [E][3][7][7]. */
+size_t lsam_patch_embed_image_bytes(int embed_dim);
+int lsam_patch_embed_pack(const float* proj_w, int embed_dim, void* image, lsam_stream_t stream);
+int lsam_patch_embed_fwd(const float* frames, const void* image, const float* proj_b, const float* pos, float* out, int N,
+                         int S, int embed_dim, lsam_stream_t stream);
+
 /* G[c][k] = sum_m X[m][c] * Y[m][k]  (k < R <= 16): the LoRA dA / dB token reductions
  * (autograd of lora_qkv.py:104-105), deterministic two-pass split over m.
  * X T [M][ldx] (C columns), Y T [M][ldy]; out fp32 at out[c*out_cs + k*out_ks];

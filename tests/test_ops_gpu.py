@@ -296,6 +296,29 @@ def test_fused_tail_block(ops, d, M, with_next):
     assert torch.equal(out2, out)
 
 
+@pytest.mark.parametrize("e0,N,S", [(112, 2, 64), (112, 1, 256), (144, 2, 96), (112, 3, 40)])
+def test_patch_embed_direct(ops, e0, N, S):
+    """PatchEmbed conv 7x7/4 pad 3 + bias + pos embed, NHWC out (backbones/utils.py:85-93, hieradet.py:307-312):
+    the direct-convolution kernel against F.conv2d on the same bf16-rounded operands (fp32 accumulation both
+    sides, so only the summation order differs).  S = 40 / 64 / 96 leave partial 8 x 32 output tiles."""
+    G = S // 4
+    frames = rnd(N, 3, S, S, seed=41)
+    w = rnd(e0, 3, 7, 7, seed=42) / 12.0
+    b = 0.2 * rnd(e0, seed=43)
+    pos = 0.5 * rnd(G, G, e0, seed=44)
+    ref = F.conv2d(frames.bfloat16().float(), w.bfloat16().float(), b, stride=4, padding=3).permute(0, 2, 3, 1) + pos
+    img = ops.patch_embed_pack(w.cuda())
+    got = ops.patch_embed_fwd(frames.cuda(), img, b.cuda(), pos.cuda())
+    assert got.shape == (N, G, G, e0)
+    assert rel_err(got.cpu(), ref) < 1e-5
+
+
+def test_patch_embed_direct_rejects_unsupported(ops):
+    from image_segmentation_amd._C import LsamError
+    with pytest.raises(LsamError):
+        ops.patch_embed_pack(rnd(160, 3, 7, 7).cuda())
+
+
 def test_fused_tail_block_rejects_unsupported(ops):
     from image_segmentation_amd._C import LsamError
     d = 112

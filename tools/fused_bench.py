@@ -17,6 +17,7 @@ def timeit(fn, R=10):
     return e0.elapsed_time(e1) * 1e3 / R
 print(os.environ.get("LSAM_LIB", "liblsam.so"))
 ONLY_TAIL = bool(os.environ.get("FB_TAIL"))
+ONLY_MLP = bool(os.environ.get("FB_MLP"))
 for d, M in ([] if ONLY_TAIL else [(112, 16 * 256 * 256), (224, 16 * 128 * 128)]):
     x = torch.randn(M, d, device=dev)
     g, b = torch.ones(d, device=dev), torch.zeros(d, device=dev)
@@ -25,7 +26,7 @@ for d, M in ([] if ONLY_TAIL else [(112, 16 * 256 * 256), (224, 16 * 128 * 128)]
     y = torch.empty_like(x)
     us = timeit(lambda: ops.mlp_block_fwd(x, g, b, img, bias, out=y))
     print(f"mlp_block d={d} M={M}: {us:8.1f} us  {16.0*M*d*d/us/1e6:7.1f} TF/s  {M*d*8/us/1e6:5.2f} TB/s")
-for nh, H in ([] if ONLY_TAIL else [(2, 256)]):
+for nh, H in ([] if ONLY_TAIL or ONLY_MLP else [(2, 256)]):
     d = nh * 56
     x = torch.randn(16, H, H, d, device=dev)
     g, b = torch.ones(d, device=dev), torch.zeros(d, device=dev)
@@ -35,7 +36,7 @@ for nh, H in ([] if ONLY_TAIL else [(2, 256)]):
     us = timeit(lambda: ops.window_block_fwd(x, g, b, img, bias, nh, out=y))
     print(f"window_block nh={nh} grid={H}: {us:8.1f} us  {x.numel()*8/us/1e6:5.2f} TB/s")
 
-for d, M in [(448, 16 * 64 * 64), (224, 16 * 128 * 128)]:
+for d, M in ([] if ONLY_MLP else [(448, 16 * 64 * 64), (224, 16 * 128 * 128)]):
     res = torch.randn(M, d, device=dev)
     a = torch.randn(M, d, device=dev).bfloat16()
     r = lambda *sh: torch.randn(*sh, device=dev)
