@@ -95,7 +95,7 @@ def test_library_geometry_matches_oracle():
 def test_library_rejects_unsupported_configs():
     from image_segmentation_amd import _C
     cfg = _C.HieraConfig()
-    cfg.dtype, cfg.img_size, cfg.embed_dim, cfg.num_heads, cfg.num_stages = 1, 256, 96, 1, 4   # head_dim 96
+    cfg.dtype, cfg.img_size, cfg.embed_dim, cfg.num_heads, cfg.num_stages = 1, 256, 144, 1, 4   # head_dim 144 > 128
     for i, (s, w) in enumerate(zip((1, 2, 7, 2), (8, 4, 14, 7))):
         cfg.stages[i], cfg.window_spec[i] = s, w
     cfg.q_pool = 3
