@@ -76,6 +76,7 @@ def lib() -> C.CDLL:
                                                 C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         vp, i, f, l = C.c_void_p, C.c_int, C.c_float, C.c_long
         L.lsam_linear.argtypes = [i, vp, i, vp, i, vp, vp, i, i, vp, i, vp, i, vp, i, i, i, i, i, vp]
+        L.lsam_linear_maxpool2x2.argtypes = [vp, i, vp, i, vp, vp, i, i, i, i, i, i, vp]
         L.lsam_pack_matrix.argtypes = [i, vp, l, l, i, i, vp, i, vp]
         L.lsam_layernorm_fwd.argtypes = [i, vp, i, vp, vp, vp, i, vp, i, i, f, vp]
         L.lsam_layernorm_bwd.argtypes = [i, vp, i, vp, i, vp, vp, vp, i, vp, i, vp, i, i, i, vp]
@@ -135,5 +136,5 @@ EXPORTED = [
     "lsam_window_block_image_bytes", "lsam_window_block_bias_floats", "lsam_window_block_pack",
     "lsam_window_block_fwd", "lsam_mlp_block_image_bytes", "lsam_mlp_block_bias_floats", "lsam_mlp_block_pack",
     "lsam_mlp_block_fwd", "lsam_tail_block_image_bytes", "lsam_tail_block_vec_floats", "lsam_tail_block_pack",
-    "lsam_tail_block_fwd", "lsam_patch_embed_image_bytes", "lsam_patch_embed_pack", "lsam_patch_embed_fwd",
+    "lsam_tail_block_fwd", "lsam_patch_embed_image_bytes", "lsam_patch_embed_pack", "lsam_patch_embed_fwd", "lsam_linear_maxpool2x2",
 ]

@@ -36,6 +36,17 @@ int lsam_linear(int dtype, const void* A, int lda, const void* W, int ldw, const
     DISPATCH(dtype, launch_gemm<float>(a, s), launch_gemm<bf16>(a, s));
 }
 
+int lsam_linear_maxpool2x2(const void* A, int lda, const void* W, int ldw, const float* bias, float* out, int ldo,
+                           int N_img, int H, int Wd, int N, int K, lsam_stream_t stream) {
+    LSAM_REQUIRE(N_img > 0 && gemm_pool_supported(H, Wd, N), LSAM_ERR_UNSUPPORTED,
+                 "linear_maxpool2x2: grid %dx%d, N %d not supported (need W %% 32 == 0, whole 256-token patches, N %% 224 == 0)",
+                 H, Wd, N);
+    GemmArgs a{A, lda, W, ldw, bias, nullptr, 0, 0, nullptr, 0, out, ldo, nullptr, 0, LSAM_EPI_OUT_F32, N_img * H * Wd, N, K};
+    a.pool_h = H;
+    a.pool_w = Wd;
+    return launch_gemm<bf16>(a, static_cast<hipStream_t>(stream));
+}
+
 int lsam_pack_matrix(int dtype, const float* src, long src_rs, long src_cs, int rows, int cols, void* dst, int ldd,
                      lsam_stream_t stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);

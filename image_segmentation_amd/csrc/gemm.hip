@@ -178,8 +178,9 @@ __device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
 // tile, issued before the epilogue) overlaps the next tile's main loop.  With one output tile per
 // workgroup every CU ran "all MFMA, then all stores" in lock-step and K <= 448 GEMMs spent ~70 % of
 // their time in that store phase.
-template <typename T, int WN, bool OUTF32>
+template <typename T, int WN, bool OUTF32, bool POOL = false>
 __global__ __launch_bounds__(256 * WN, 2) void gemm2_kernel(const GemmArgs p) {
+    static_assert(!POOL || (WN == 2 && OUTF32 && sizeof(T) == 2), "pooled epilogue: bf16, 256 x 224 tile, fp32 out");
     constexpr int EPC = Tr<T>::EPC, CPF = Tr<T>::CPF;
     constexpr int MT = 4, NT = 7, BM = 256, BN = 112 * WN, ROWS = BM + BN, NW = 4 * WN;
     constexpr int BK = 8 * EPC, KS = 8 / (4 * CPF);
@@ -211,7 +212,13 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm2_kernel(const GemmArgs p) {
                                                          (int)(((size_t)(M - 1) * p.lda + K) * sizeof(T)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Wt), 0,
                                                          (int)(((size_t)(N - 1) * p.ldw + K) * sizeof(T)), 0x00020000);
-    struct TileAddr { int m0, n0, arow0, wrow0; unsigned aoff0, woff0; };
+    // POOL: the 256 rows of an output tile are a TH x TW patch of the token grid (TW = min(W, 128), TH = 256 / TW)
+    // laid out so that wave row-block wm owns a 2-row x 32-column sub-patch: tile row 64 wm + 16 mt + lr is token
+    // (y0 + 2 wy + (mt >> 1), x0 + 32 wx + 16 (mt & 1) + lr), (wx, wy) = (wm % (TW/32), wm / (TW/32)).  The four
+    // partners of a 2x2 pool are then two accumulator tiles (mt, mt + 2) of ONE lane and its neighbour lane lr ^ 1.
+    const int pTW = POOL ? (p.pool_w < 128 ? p.pool_w : 128) : 1, pTH = POOL ? BM / pTW : 1, pWX = POOL ? pTW / 32 : 1;
+    const int ptx = POOL ? p.pool_w / pTW : 1, pty = POOL ? p.pool_h / pTH : 1;
+    struct TileAddr { int m0, n0, arow0, wrow0; unsigned aoff0, woff0; unsigned aoffp[POOL ? A_IT : 1]; int pn, py0, px0; };
     auto tile_addr = [&](int t) {
         TileAddr a;
         a.m0 = (t / tiles_n) * BM;
@@ -220,6 +227,19 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm2_kernel(const GemmArgs p) {
         a.wrow0 = a.n0 + 8 * wave + lrow;
         a.aoff0 = ((unsigned)a.arow0 * (unsigned)p.lda + ck) * (unsigned)sizeof(T);
         a.woff0 = ((unsigned)a.wrow0 * (unsigned)p.ldw + ck) * (unsigned)sizeof(T);
+        if constexpr (POOL) {
+            const int tm = t / tiles_n;
+            a.pn = tm / (ptx * pty);
+            a.py0 = ((tm / ptx) % pty) * pTH;
+            a.px0 = (tm % ptx) * pTW;
+            // DMA instruction j = wave + 8 i covers tile rows 8 j .. 8 j + 7: wm = i, mt = wave >> 1, half = wave & 1
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int y = a.py0 + 2 * (i / pWX) + (wave >> 2), x = a.px0 + 32 * (i % pWX) + 16 * ((wave >> 1) & 1) + 8 * (wave & 1) + lrow;
+                const unsigned tok = ((unsigned)a.pn * (unsigned)p.pool_h + (unsigned)y) * (unsigned)p.pool_w + (unsigned)x;
+                a.aoffp[i] = (tok * (unsigned)p.lda + ck) * (unsigned)sizeof(T);
+            }
+        }
         return a;
     };
     auto read_frag = [&](const char* base, int row, int c0) -> frag {
@@ -238,7 +258,9 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm2_kernel(const GemmArgs p) {
         char* base = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            const unsigned vo = (ta.arow0 + 8 * NW * i < M && kok) ? ta.aoff0 + i * astep + kb : 0xFFFFFFFFu;
+            unsigned vo;
+            if constexpr (POOL) vo = kok ? ta.aoffp[i] + kb : 0xFFFFFFFFu;   // whole patches only: every row exists
+            else vo = (ta.arow0 + 8 * NW * i < M && kok) ? ta.aoff0 + i * astep + kb : 0xFFFFFFFFu;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_ptr_t)(base + (wave + NW * i) * 1024), 16, vo, 0, 0, 0);
         }
 #pragma unroll
@@ -382,6 +404,30 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm2_kernel(const GemmArgs p) {
             else store_row(static_cast<bf16*>(p.out), p.ldo, v);
         }
     };
+    // POOL epilogue: out[pooled token][n] = max over the 2x2 token patch (the bias is already in the accumulators
+    // and is the same for the four partners).  Even lanes store 16 bytes; rows = the pooled grid [N][H/2][W/2].
+    auto epilogue_pool = [&](const TileAddr& ta) {
+        int lr = lr_c, g = g_c;
+        asm volatile("" : "+v"(lr), "+v"(g));
+        const int nc = ta.n0 + wn * 112 + 4 * g;
+        const int hh = p.pool_h >> 1, hw = p.pool_w >> 1;
+#pragma unroll
+        for (int mp = 0; mp < 2; ++mp) {
+            const int py = (ta.py0 >> 1) + wm / pWX, px = (ta.px0 + 32 * (wm % pWX) + 16 * mp + lr) >> 1;
+            float* rowp = static_cast<float*>(p.out) + (((size_t)ta.pn * hh + py) * hw + px) * p.ldo + nc;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a = fmaxf(acc[mp][nt][r], acc[mp + 2][nt][r]);
+                    const float b = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+                    v[r] = fmaxf(a, b);
+                }
+                if (!(lr & 1)) store4(rowp + 16 * nt, v);
+            }
+        }
+    };
     // the accumulators start at the bias (one batched read per output tile) instead of zero
     auto init_acc = [&](int n0) {
         f32x4 bv[NT];
@@ -446,7 +492,8 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm2_kernel(const GemmArgs p) {
 #endif
                 st ^= 1;
             }
-            epilogue(ta.m0, ta.n0);
+            if constexpr (POOL) epilogue_pool(ta);
+            else epilogue(ta.m0, ta.n0);
             ta = tb;
             t = tn;
         }
@@ -532,9 +579,9 @@ static int launch_cfg(const GemmArgs& a, hipStream_t s) {
     return LSAM_OK;
 }
 
-template <typename T, int WN, bool OUTF32> static int launch_v2(const GemmArgs& a, hipStream_t s) {
+template <typename T, int WN, bool OUTF32, bool POOL = false> static int launch_v2(const GemmArgs& a, hipStream_t s) {
     constexpr int LDS = WN * (256 + 112 * WN) * 128;
-    auto kern = gemm2_kernel<T, WN, OUTF32>;
+    auto kern = gemm2_kernel<T, WN, OUTF32, POOL>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         LSAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -557,6 +604,14 @@ template <typename T, int WN, bool OUTF32> static int launch_v2(const GemmArgs& 
     return LSAM_OK;
 }
 
+// pooled epilogue: whole TH x TW patches (TW = min(W, 128) a multiple of 32, TH = 256 / TW), 224-wide column tiles
+bool gemm_pool_supported(int H, int W, int N) {
+    if (H <= 0 || W <= 0 || W % 32 != 0 || N % 224 != 0) return false;
+    const int tw = W < 128 ? W : 128;
+    if (tw != 32 && tw != 64 && tw != 128) return false;
+    return W % tw == 0 && H % (256 / tw) == 0;
+}
+
 template <typename T> int launch_gemm(const GemmArgs& a, hipStream_t s) {
     constexpr int EPC = Tr<T>::EPC;
     LSAM_REQUIRE(a.A && a.W && a.out, LSAM_ERR_BAD_ARG, "linear: null operand");
@@ -573,6 +628,18 @@ template <typename T> int launch_gemm(const GemmArgs& a, hipStream_t s) {
                  "linear: GELU_BWD needs aux");
     LSAM_REQUIRE(!(a.flags & LSAM_EPI_SAVE_PRE) || (a.out2 && a.ldo2 % 4 == 0), LSAM_ERR_BAD_ARG,
                  "linear: SAVE_PRE needs out2");
+    if (a.pool_w > 0) {
+        if constexpr (sizeof(T) == 2) {
+            LSAM_REQUIRE(gemm_pool_supported(a.pool_h, a.pool_w, a.N) && a.M % (a.pool_h * a.pool_w) == 0 &&
+                             (a.flags & ~LSAM_EPI_OUT_F32) == 0 && (a.flags & LSAM_EPI_OUT_F32) && !a.res &&
+                             (double)a.M * a.lda * sizeof(T) < 2.0e9 && (double)a.N * a.ldw * sizeof(T) < 2.0e9,
+                         LSAM_ERR_UNSUPPORTED, "linear: pooled epilogue not available for this shape");
+            return launch_v2<T, 2, true, true>(a, s);
+        } else {
+            set_error("linear: pooled epilogue is bf16 only");
+            return LSAM_ERR_UNSUPPORTED;
+        }
+    }
     if (a.N % 112 == 0 && (double)a.M * a.lda * sizeof(T) < 2.0e9 && (double)a.N * a.ldw * sizeof(T) < 2.0e9 && a.M >= 1024 &&
         a.ldo % 8 == 0 && (!(a.flags & LSAM_EPI_SAVE_PRE) || (a.ldo2 % 8 == 0 && aligned16(a.out2))))
     {

@@ -304,10 +304,19 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
         else y = x;
         const float* res = x;
         if (d != q) {  // shortcut = pool(proj(norm1(x)))  (hieradet.py:139-140)
-            float* sc = g.pool == 2 ? at<float>(ws, w.scpre) : y;
-            LSAM_TRY(linear<T>(xn, g.kq, at<T>(arena, o.wsc), d, at<float>(arena, o.bsc), nullptr, 0, 0, nullptr, 0, sc,
-                               q, nullptr, 0, LSAM_EPI_OUT_F32, Mi, q, d, s));
-            if (g.pool == 2) LSAM_TRY(launch_maxpool2x2(sc, y, N, g.gin, g.gin, q, s));
+            if (g.pool == 2 && sizeof(T) == 2 && gemm_pool_supported(g.gin, g.gin, q)) {
+                // the 2x2 max-pool is taken in the GEMM's epilogue: the full-resolution fp32 product never exists
+                GemmArgs ga{xn, g.kq, at<T>(arena, o.wsc), d, at<float>(arena, o.bsc), nullptr, 0, 0, nullptr, 0, y, q,
+                            nullptr, 0, LSAM_EPI_OUT_F32, Mi, q, d};
+                ga.pool_h = g.gin;
+                ga.pool_w = g.gin;
+                LSAM_TRY(launch_gemm<T>(ga, s));
+            } else {
+                float* sc = g.pool == 2 ? at<float>(ws, w.scpre) : y;
+                LSAM_TRY(linear<T>(xn, g.kq, at<T>(arena, o.wsc), d, at<float>(arena, o.bsc), nullptr, 0, 0, nullptr, 0, sc,
+                                   q, nullptr, 0, LSAM_EPI_OUT_F32, Mi, q, d, s));
+                if (g.pool == 2) LSAM_TRY(launch_maxpool2x2(sc, y, N, g.gin, g.gin, q, s));
+            }
             res = y;
         }
         // ---- qkv (+LoRA through the augmented K columns) ------------------------------------------

@@ -14,7 +14,11 @@ struct GemmArgs {
     void* out2; int ldo2;
     int flags;
     int M, N, K;
+    // optional 2x2 max-pool of the OUTPUT rows (rows = tokens of an [pool_n][pool_h][pool_w] grid, M = their
+    // product): out then has M / 4 rows.  bf16 operands, fp32 out, N % 224 == 0, bias only (see gemm_pool_supported).
+    int pool_h = 0, pool_w = 0;
 };
+bool gemm_pool_supported(int H, int W, int N);
 template <typename T> int launch_gemm(const GemmArgs& a, hipStream_t s);
 int prof_arm(int capacity);
 int prof_read(int max, float* ms, double* flops, int* cfg, int* mnk);

@@ -66,6 +66,19 @@ def linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None
     return (out, out2) if save_pre else out
 
 
+def linear_maxpool2x2(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, n_img: int, H: int, Wd: int):
+    """fp32 [n_img, H/2, Wd/2, N] = MaxPool2d(2,2)(A @ W.T + bias) over the token grid (see lsam_linear_maxpool2x2)."""
+    _need_gpu(A, W, bias)
+    assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16
+    M, K, lda = _rows2d(A)
+    N, Kw, ldw = _rows2d(W)
+    assert M == n_img * H * Wd and K == Kw
+    b = bias.detach().float().contiguous()
+    out = torch.empty(n_img, H // 2, Wd // 2, N, dtype=torch.float32, device=A.device)
+    check(lib().lsam_linear_maxpool2x2(ptr(A), lda, ptr(W), ldw, ptr(b), ptr(out), N, n_img, H, Wd, N, K, stream()))
+    return out
+
+
 def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, dtype: torch.dtype,
                   ld: Optional[int] = None, want_stats: bool = False, eps: float = 1e-6):
     _need_gpu(x, gamma, beta)

@@ -129,6 +129,15 @@ int lsam_cast(int dtype, const float* src, int lds, void* dst, int ldd, int rows
 int lsam_im2col_patch(int dtype, const float* img, void* cols, int ldc, int N, int S,
                       lsam_stream_t stream);
 
+/* Shortcut of a q-pool block in one kernel: out = MaxPool2d(2, 2)(A . W^T + bias) over the token grid
+ * (`shortcut = do_pool(self.proj(x_norm), self.pool)`, hieradet.py:139-140; do_pool: hieradet.py:27-41).
+ * A bf16 [N_img*H*W][lda] (rows = NHWC tokens), W bf16 [N][ldw], bias fp32 [N]; out fp32 [N_img*(H/2)*(W/2)][ldo].
+ * The full-resolution product never exists in memory: the pool is taken over accumulator tiles in the epilogue.
+ * Needs W % 32 == 0, whole 256-token patches (min(W,128) wide) and N % 224 == 0, else LSAM_ERR_UNSUPPORTED
+ * (callers then use lsam_linear + lsam_maxpool2x2). */
+int lsam_linear_maxpool2x2(const void* A, int lda, const void* W, int ldw, const float* bias, float* out, int ldo,
+                           int N_img, int H, int Wd, int N, int K, lsam_stream_t stream);
+
 /* PatchEmbed + position embedding in one kernel (bf16 MFMA, fp32 out), no column matrix in memory:
  *   out[n][oy][ox][:] = Conv2d(3, E, kernel 7, stride 4, padding 3)(frames)[n, :, oy, ox] + proj_b + pos[oy][ox][:]
  * (PatchEmbed.forward, backbones/utils.py:85-93, incl. its NCHW -> NHWC permute, and the `x = x + self._get_pos_embed(...)`

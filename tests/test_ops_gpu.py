@@ -319,6 +319,28 @@ def test_patch_embed_direct_rejects_unsupported(ops):
         ops.patch_embed_pack(rnd(160, 3, 7, 7).cuda())
 
 
+@pytest.mark.parametrize("n_img,H,Wd,N,K", [(2, 16, 32, 224, 112), (1, 8, 64, 448, 224), (2, 4, 128, 224, 112),
+                                            (1, 256, 256, 224, 112), (3, 8, 32, 896, 448)])
+def test_linear_maxpool2x2(ops, n_img, H, Wd, N, K):
+    """shortcut = do_pool(proj(x_norm)) (hieradet.py:139-140, 27-41) with the pool in the GEMM epilogue, against
+    F.max_pool2d of the un-pooled fp32 product of the same bf16 operands."""
+    A = rnd(n_img * H * Wd, K, seed=51).bfloat16()
+    W = (rnd(N, K, seed=52) / math.sqrt(K)).bfloat16()
+    b = 0.3 * rnd(N, seed=53)
+    full = (A.float() @ W.float().t() + b).view(n_img, H, Wd, N).permute(0, 3, 1, 2)
+    ref = F.max_pool2d(full, 2, 2).permute(0, 2, 3, 1)
+    got = ops.linear_maxpool2x2(A.cuda(), W.cuda(), b.cuda(), n_img, H, Wd)
+    assert got.shape == ref.shape
+    assert rel_err(got.cpu(), ref) < 1e-5
+
+
+def test_linear_maxpool2x2_rejects_unsupported(ops):
+    from image_segmentation_amd._C import LsamError
+    A, W, b = rnd(16 * 16, 112).bfloat16().cuda(), rnd(224, 112).bfloat16().cuda(), rnd(224).cuda()
+    with pytest.raises(LsamError):
+        ops.linear_maxpool2x2(A, W, b, 1, 16, 16)   # 16-wide grid: no whole 32-column patch
+
+
 def test_fused_tail_block_rejects_unsupported(ops):
     from image_segmentation_amd._C import LsamError
     d = 112
