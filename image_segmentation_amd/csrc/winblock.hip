@@ -191,14 +191,25 @@ __global__ __launch_bounds__(256, 1) void winblock_attn_kernel(const WinBlockArg
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = b;
                 }
+                // weight fragments one k-step (4 row tiles) ahead of the MFMAs that use them: with one wave per
+                // SIMD a read that is waited for right before its MFMAs exposes the whole LDS latency
+                bf16x8 wb[2][4];
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
+                for (int nt = 0; nt < 4; ++nt) wb[0][nt] = wfrag(((s * NH + h) * NH) * I::SUB, 16 * nt + lr, g);
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
-                        const bf16x8 wf = wfrag(((s * NH + h) * NH + (ks >> 1)) * I::SUB, 16 * nt + lr, (ks & 1) * 4 + g);
+                for (int ks = 0; ks < KS; ++ks) {
+                    if (ks + 1 < KS) {
 #pragma unroll
-                        for (int mt = 0; mt < 4; ++mt) mma16(wf, xn[mt][ks], acc[mt][nt]);
+                        for (int nt = 0; nt < 4; ++nt)
+                            wb[(ks + 1) & 1][nt] = wfrag(((s * NH + h) * NH + ((ks + 1) >> 1)) * I::SUB, 16 * nt + lr, ((ks + 1) & 1) * 4 + g);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) mma16(wb[ks & 1][nt], xn[mt][ks], acc[mt][nt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -220,14 +231,23 @@ __global__ __launch_bounds__(256, 1) void winblock_attn_kernel(const WinBlockArg
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = f32x4{b, b, b, b};
                 }
+                bf16x8 wb[2][4];
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
+                for (int nt = 0; nt < 4; ++nt) wb[0][nt] = wfrag(((2 * NH + h) * NH) * I::SUB, 16 * nt + lr, g);
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
-                        const bf16x8 wf = wfrag(((2 * NH + h) * NH + (ks >> 1)) * I::SUB, 16 * nt + lr, (ks & 1) * 4 + g);
+                for (int ks = 0; ks < KS; ++ks) {
+                    if (ks + 1 < KS) {
 #pragma unroll
-                        for (int mt = 0; mt < 4; ++mt) mma16(xn[mt][ks], wf, acc[mt][nt]);
+                        for (int nt = 0; nt < 4; ++nt)
+                            wb[(ks + 1) & 1][nt] = wfrag(((2 * NH + h) * NH + ((ks + 1) >> 1)) * I::SUB, 16 * nt + lr, ((ks + 1) & 1) * 4 + g);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) mma16(xn[mt][ks], wb[ks & 1][nt], acc[mt][nt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -307,18 +327,25 @@ __global__ __launch_bounds__(256, 1) void winblock_attn_kernel(const WinBlockArg
                 for (int mt = 0; mt < 4; ++mt)
                     acc[mt][q] = ok ? load4(p.x + tok_row(mt * 16 + lr) * D + c0) + b : zero4;
             }
+            {   // (head, k-half) steps of NTH fragments, read one step ahead (tiles past D hold zero weights)
+                bf16x8 wb[2][NTH];
 #pragma unroll
-            for (int h = 0; h < NH; ++h)
+                for (int q = 0; q < NTH; ++q) wb[0][q] = wfrag(I::QKV_B, 16 * (half * NTH + q) + lr, g);
 #pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2)
+                for (int st = 0; st < 2 * NH; ++st) {
+                    if (st + 1 < 2 * NH) {
 #pragma unroll
-                    for (int q = 0; q < NTH; ++q) {
-                        const int nt = half * NTH + q;
-                        if (16 * nt >= D) continue;   // uniform
-                        const bf16x8 wf = wfrag(I::QKV_B + h * (I::NP * 128), 16 * nt + lr, k2 * 4 + g);
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt) mma16(wf, of[h][mt][k2], acc[mt][q]);
+                        for (int q = 0; q < NTH; ++q)
+                            wb[(st + 1) & 1][q] = wfrag(I::QKV_B + ((st + 1) >> 1) * (I::NP * 128), 16 * (half * NTH + q) + lr, ((st + 1) & 1) * 4 + g);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < NTH; ++q)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) mma16(wb[st & 1][q], of[st >> 1][mt][st & 1], acc[mt][q]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
 #pragma unroll
             for (int q = 0; q < NTH; ++q) {
                 const int c0 = 16 * (half * NTH + q) + 4 * g;
