@@ -54,7 +54,8 @@ def lib() -> C.CDLL:
         for name in ("lsam_hiera_arena_bytes", "lsam_hiera_workspace_bytes", "lsam_outer_reduce_ws",
                      "lsam_window_block_image_bytes", "lsam_window_block_bias_floats",
                      "lsam_mlp_block_image_bytes", "lsam_mlp_block_bias_floats",
-                     "lsam_tail_block_image_bytes", "lsam_tail_block_vec_floats", "lsam_patch_embed_image_bytes"):
+                     "lsam_tail_block_image_bytes", "lsam_tail_block_vec_floats", "lsam_patch_embed_image_bytes",
+                     "lsam_lateral_conv_image_bytes"):
             getattr(L, name).restype = C.c_size_t
         L.lsam_hiera_arena_bytes.argtypes = [C.c_void_p]
         L.lsam_hiera_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -91,6 +92,9 @@ def lib() -> C.CDLL:
                      "lsam_mlp_block_image_bytes", "lsam_mlp_block_bias_floats",
                      "lsam_tail_block_image_bytes", "lsam_tail_block_vec_floats", "lsam_patch_embed_image_bytes"):
             getattr(L, name).argtypes = [i]
+        L.lsam_lateral_conv_image_bytes.argtypes = [i, i]
+        L.lsam_lateral_conv_pack.argtypes = [vp, i, i, vp, vp]
+        L.lsam_lateral_conv_fwd.argtypes = [vp, vp, vp, vp, i, i, i, vp]
         L.lsam_patch_embed_pack.argtypes = [vp, i, vp, vp]
         L.lsam_patch_embed_fwd.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp]
         L.lsam_tail_block_pack.argtypes = [vp] * 8 + [i, vp, vp, vp]
@@ -137,4 +141,5 @@ EXPORTED = [
     "lsam_window_block_fwd", "lsam_mlp_block_image_bytes", "lsam_mlp_block_bias_floats", "lsam_mlp_block_pack",
     "lsam_mlp_block_fwd", "lsam_tail_block_image_bytes", "lsam_tail_block_vec_floats", "lsam_tail_block_pack",
     "lsam_tail_block_fwd", "lsam_patch_embed_image_bytes", "lsam_patch_embed_pack", "lsam_patch_embed_fwd", "lsam_linear_maxpool2x2",
+    "lsam_lateral_conv_image_bytes", "lsam_lateral_conv_pack", "lsam_lateral_conv_fwd",
 ]

@@ -117,6 +117,17 @@ int lsam_patch_embed_fwd(const float* frames, const void* image, const float* pr
     return launch_patch_embed(frames, image, proj_b, pos, out, N, S, embed_dim, static_cast<hipStream_t>(stream));
 }
 
+size_t lsam_lateral_conv_image_bytes(int in_channels, int out_channels) {
+    return lateral_supported(in_channels, out_channels) ? lateral_image_bytes(in_channels, out_channels) : 0;
+}
+int lsam_lateral_conv_pack(const float* weight, int in_channels, int out_channels, void* image, lsam_stream_t stream) {
+    return launch_pack_lateral(weight, in_channels, out_channels, image, static_cast<hipStream_t>(stream));
+}
+int lsam_lateral_conv_fwd(const float* x, const void* image, const float* bias, void* out, int M, int in_channels,
+                          int out_channels, lsam_stream_t stream) {
+    return launch_lateral(x, image, bias, out, M, in_channels, out_channels, static_cast<hipStream_t>(stream));
+}
+
 size_t lsam_window_block_image_bytes(int nh) { return (nh == 1 || nh == 2) ? winblock_image_bytes(nh) : 0; }
 size_t lsam_window_block_bias_floats(int nh) { return (nh == 1 || nh == 2) ? winblock_bias_floats(nh) : 0; }
 int lsam_window_block_pack(const float* qkv_w, const float* qkv_b, const float* proj_w, const float* proj_b, int nh,

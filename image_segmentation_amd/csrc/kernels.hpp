@@ -70,6 +70,12 @@ int launch_pack_patch_embed(const float* w, int e0, void* img, hipStream_t s);
 int launch_patch_embed(const float* frames, const void* wimg, const float* bias, const float* pos, float* out, int N, int S,
                        int e0, hipStream_t s);
 
+// FPN lateral 1x1 convolution from the fp32 stage output, bf16 out (lateral.hip)
+bool lateral_supported(int K, int N);
+size_t lateral_image_bytes(int K, int N);
+int launch_pack_lateral(const float* w, int K, int N, void* img, hipStream_t s);
+int launch_lateral(const float* x, const void* img, const float* bias, void* out, int M, int K, int N, hipStream_t s);
+
 // fused attention half of a same-dim 8x8-window block (winblock.hip)
 struct WinBlockArgs {
     const float* x;       // [N*H*W][D] fp32 residual stream (D = nh * hd)

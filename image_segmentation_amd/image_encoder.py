@@ -80,9 +80,13 @@ class _Conv1x1Fn(torch.autograd.Function):
     def forward(ctx, x_nhwc, weight, bias, dt):
         N, H, W, Cc = x_nhwc.shape
         co = weight.shape[0]
-        xt = ops.cast(x_nhwc.reshape(-1, Cc), dt)
-        wt = ops.pack_matrix(weight.detach().reshape(co, Cc), dt)
-        out = ops.linear(xt, wt, bias.detach())
+        if dt == torch.bfloat16 and x_nhwc.dtype == torch.float32 and ops.lateral_conv_supported(Cc, co):
+            # high-resolution levels: one kernel from the fp32 stage output (no bf16 copy of x in memory)
+            out = ops.lateral_conv(x_nhwc.reshape(-1, Cc), weight, bias)
+        else:
+            xt = ops.cast(x_nhwc.reshape(-1, Cc), dt)
+            wt = ops.pack_matrix(weight.detach().reshape(co, Cc), dt)
+            out = ops.linear(xt, wt, bias.detach())
         ctx.save_for_backward(weight)
         ctx.dt, ctx.shape = dt, (N, H, W, Cc)
         return out.view(N, H, W, co)

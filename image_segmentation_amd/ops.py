@@ -236,6 +236,28 @@ def mlp_block_fwd(x, norm2_w, norm2_b, img, bias, eps: float = 1e-6, out=None):
     return y
 
 
+def lateral_conv_supported(in_channels: int, out_channels: int) -> bool:
+    return lib().lsam_lateral_conv_image_bytes(in_channels, out_channels) > 0
+
+
+def lateral_conv(x2d: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor):
+    """bf16 [M, 256] = x2d (fp32 [M, K]) @ weight.T + bias in one kernel (see lsam_lateral_conv_fwd)."""
+    _need_gpu(x2d, weight, bias)
+    assert x2d.dtype == torch.float32 and x2d.is_contiguous() and x2d.dim() == 2
+    M, K = x2d.shape
+    co = weight.shape[0]
+    nbytes = lib().lsam_lateral_conv_image_bytes(K, co)
+    if nbytes == 0:
+        raise _C.LsamError(f"lateral conv: {K} -> {co} channels not supported")
+    img = torch.empty(nbytes, dtype=torch.uint8, device=x2d.device)
+    w = weight.detach().float().reshape(co, K).contiguous()
+    b = bias.detach().float().contiguous()
+    check(lib().lsam_lateral_conv_pack(ptr(w), K, co, ptr(img), stream()))
+    out = torch.empty(M, co, dtype=torch.bfloat16, device=x2d.device)
+    check(lib().lsam_lateral_conv_fwd(ptr(x2d), ptr(img), ptr(b), ptr(out), M, K, co, stream()))
+    return out
+
+
 def patch_embed_pack(proj_w):
     """PatchEmbed proj.weight [E,3,7,7] fp32 -> fragment-order bf16 weight image of the direct convolution."""
     _need_gpu(proj_w)

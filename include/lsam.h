@@ -129,6 +129,16 @@ int lsam_cast(int dtype, const float* src, int lds, void* dst, int ldd, int rows
 int lsam_im2col_patch(int dtype, const float* img, void* cols, int ldc, int N, int S,
                       lsam_stream_t stream);
 
+/* Lateral 1x1 convolution of the FPN neck straight from an fp32 stage output, bf16 MFMA, bf16 out:
+ *   out[m][:] = x[m][:] . weight^T + bias      (FpnNeck.forward, image_encoder.py:107-110, kernel_size 1;
+ *   x = the NHWC tokens of a trunk stage, fp32 [M][in_channels]; weight fp32 [out_channels][in_channels]).
+ * Replaces the fp32 -> bf16 copy of x plus lsam_linear for the high-resolution levels.
+ * out_channels == 256 and in_channels % 8 == 0, 16 <= in_channels <= 224; otherwise 0 bytes / LSAM_ERR_UNSUPPORTED. */
+size_t lsam_lateral_conv_image_bytes(int in_channels, int out_channels);
+int lsam_lateral_conv_pack(const float* weight, int in_channels, int out_channels, void* image, lsam_stream_t stream);
+int lsam_lateral_conv_fwd(const float* x, const void* image, const float* bias, void* out, int M, int in_channels,
+                          int out_channels, lsam_stream_t stream);
+
 /* Shortcut of a q-pool block in one kernel: out = MaxPool2d(2, 2)(A . W^T + bias) over the token grid
  * (`shortcut = do_pool(self.proj(x_norm), self.pool)`, hieradet.py:139-140; do_pool: hieradet.py:27-41).
  * A bf16 [N_img*H*W][lda] (rows = NHWC tokens), W bf16 [N][ldw], bias fp32 [N]; out fp32 [N_img*(H/2)*(W/2)][ldo].

@@ -341,6 +341,24 @@ def test_linear_maxpool2x2_rejects_unsupported(ops):
         ops.linear_maxpool2x2(A, W, b, 1, 16, 16)   # 16-wide grid: no whole 32-column patch
 
 
+@pytest.mark.parametrize("M,K", [(4096, 112), (1000, 224), (777, 144), (64, 16)])
+def test_lateral_conv(ops, M, K):
+    """FpnNeck lateral 1x1 conv (image_encoder.py:107-110) from the fp32 stage output: against the fp32 product of
+    the bf16-rounded operands, rounded to bf16."""
+    x = rnd(M, K, seed=61)
+    w = rnd(256, K, seed=62) / math.sqrt(K)
+    b = 0.3 * rnd(256, seed=63)
+    ref = (x.bfloat16().float() @ w.bfloat16().float().t() + b)
+    got = ops.lateral_conv(x.cuda(), w.cuda(), b.cuda())
+    assert got.dtype == torch.bfloat16 and got.shape == (M, 256)
+    assert rel_err(got.float().cpu(), ref) < 3e-3   # bf16 output rounding
+
+
+def test_lateral_conv_unsupported_widths(ops):
+    assert not ops.lateral_conv_supported(448, 256) and not ops.lateral_conv_supported(112, 128)
+    assert ops.lateral_conv_supported(112, 256) and ops.lateral_conv_supported(224, 256)
+
+
 def test_fused_tail_block_rejects_unsupported(ops):
     from image_segmentation_amd._C import LsamError
     d = 112
