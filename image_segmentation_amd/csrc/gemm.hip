@@ -163,6 +163,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
 #ifndef LSAM_ABL
 #define LSAM_ABL 0
 #endif
+// 1: issue the next k-tile's DMA instructions between groups of MFMAs instead of in one burst in front of them.
+// Measured on the stage-3 qkv shape (65536 x 1344 x 480): 125 us spread vs 114 us burst -- the loop is bound by
+// the L2 -> LDS stream and the epilogue, not by DMA issue slots, and the burst starts that stream earlier.
+#ifndef GEMM2_SPREAD_DMA
+#define GEMM2_SPREAD_DMA 0
+#endif
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 __device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
@@ -266,6 +272,30 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm2_kernel(const GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < W_IT; ++i) {
             const int j = wave + NW * i;
+            if (j < W_INSTR) {
+                const unsigned vo = (ta.wrow0 + 8 * NW * i < N && kok) ? ta.woff0 + i * wstep + kb : 0xFFFFFFFFu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(base + (32 + j) * 1024), 16, vo, 0, 0, 0);
+            }
+        }
+    };
+
+    // one DMA wave-instruction of a k-tile: idx < A_IT -> A piece idx, else W piece idx - A_IT
+    auto issue_piece = [&](const TileAddr& ta, int kt, int buf, int idx) {
+#if LSAM_ABL & 1
+        return;
+#endif
+        const int k0 = kt * BK;
+        const bool kok = k0 + ck < K;
+        const unsigned kb = (unsigned)k0 * (unsigned)sizeof(T);
+        char* base = smem + buf * STAGE;
+        if (idx < A_IT) {
+            const int i = idx;
+            unsigned vo;
+            if constexpr (POOL) vo = kok ? ta.aoffp[i] + kb : 0xFFFFFFFFu;
+            else vo = (ta.arow0 + 8 * NW * i < M && kok) ? ta.aoff0 + i * astep + kb : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_ptr_t)(base + (wave + NW * i) * 1024), 16, vo, 0, 0, 0);
+        } else {
+            const int i = idx - A_IT, j = wave + NW * i;
             if (j < W_INSTR) {
                 const unsigned vo = (ta.wrow0 + 8 * NW * i < N && kok) ? ta.woff0 + i * wstep + kb : 0xFFFFFFFFu;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(base + (32 + j) * 1024), 16, vo, 0, 0, 0);
@@ -483,13 +513,34 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm2_kernel(const GemmArgs p) {
                 if constexpr (HOIST) load_frags(st, af, wf);
 #endif
                 __builtin_amdgcn_sched_barrier(0);
-                if (kt + 1 < nkt) issue(ta, kt + 1, st ^ 1);
-                else if (tn < ntiles) issue(tb, 0, st ^ 1);   // next output tile's first k-tile
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (HOIST && GEMM2_SPREAD_DMA) {
+                    // the DMA instructions of the next k-tile are issued between groups of MFMAs (their issue cost
+                    // falls into MFMA shadows) instead of in one burst in front of them.  No LDS read follows them
+                    // before the next barrier, so hipcc has no reason to drain vmcnt early.
+                    constexpr int NPIECE = A_IT + W_IT, NMMA = KS * NT * MT, PER = (NMMA + NPIECE - 1) / NPIECE;
+                    const bool same = kt + 1 < nkt, nexttile = !same && tn < ntiles;
+#pragma unroll
+                    for (int c = 0; c < NPIECE; ++c) {
+                        if (same) issue_piece(ta, kt + 1, st ^ 1, c);
+                        else if (nexttile) issue_piece(tb, 0, st ^ 1, c);
 #if !(LSAM_ABL & 2)
-                if constexpr (HOIST) mfmas(af, wf);
-                else compute_interleaved(st);
+#pragma unroll
+                        for (int e = c * PER; e < (c + 1) * PER && e < NMMA; ++e) {
+                            const int ks = e / (NT * MT), nt = (e % (NT * MT)) / MT, mt = e % MT;
+                            mma16(wf[ks][nt], af[ks][mt], acc[mt][nt]);
+                        }
 #endif
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                    if (kt + 1 < nkt) issue(ta, kt + 1, st ^ 1);
+                    else if (tn < ntiles) issue(tb, 0, st ^ 1);   // next output tile's first k-tile
+                    __builtin_amdgcn_sched_barrier(0);
+#if !(LSAM_ABL & 2)
+                    if constexpr (HOIST) mfmas(af, wf);
+                    else compute_interleaved(st);
+#endif
+                }
                 st ^= 1;
             }
             if constexpr (POOL) epilogue_pool(ta);
