@@ -695,7 +695,10 @@ template <typename T> int launch_gemm(const GemmArgs& a, hipStream_t s) {
         a.ldo % 8 == 0 && (!(a.flags & LSAM_EPI_SAVE_PRE) || (a.ldo2 % 8 == 0 && aligned16(a.out2))))
     {
         const bool of32 = (a.flags & LSAM_EPI_OUT_F32) || sizeof(T) == 4;
-        if (a.N % 224 == 0) return of32 ? launch_v2<T, 2, true>(a, s) : launch_v2<T, 2, sizeof(T) == 4>(a, s);
+#ifndef GEMM2_FORCE_WN1
+#define GEMM2_FORCE_WN1 0
+#endif
+        if (a.N % 224 == 0 && !GEMM2_FORCE_WN1) return of32 ? launch_v2<T, 2, true>(a, s) : launch_v2<T, 2, sizeof(T) == 4>(a, s);
         return of32 ? launch_v2<T, 1, true>(a, s) : launch_v2<T, 1, sizeof(T) == 4>(a, s);
     }
     if (a.N % 112 == 0) return launch_cfg<T, 2, 7, 4, 1>(a, s);

@@ -162,11 +162,11 @@ __global__ __launch_bounds__(64 * NW, WPC) void tailblock_kernel(const TailBlock
 #endif
         constexpr int b = decltype(b_)::value, NBT = decltype(nbt_)::value;
         constexpr int NP = NF / NW, PPB = (NP + NBT - 1) / NBT;   // full pieces per wave, pieces per batch
-#pragma unroll
-        for (int i = b * PPB; i < (b + 1) * PPB && i < NP; ++i) issue_piece(ck, buf, i);
-        if constexpr (NF % NW != 0 && b == NBT - 1) {
+        if constexpr (NF % NW != 0 && b == 0) {   // the odd piece first: whatever is issued last is what the next barrier waits for
             if (wave + NW * NP < NF) issue_piece(ck, buf, NP);
         }
+#pragma unroll
+        for (int i = b * PPB; i < (b + 1) * PPB && i < NP; ++i) issue_piece(ck, buf, i);
     };
     auto issue = [&](int ck, int buf) {   // whole chunk at once (kernel start only)
         static_for<0, 4>([&](auto b_) { issue_part(b_, std::integral_constant<int, 4>{}, ck, buf); });
