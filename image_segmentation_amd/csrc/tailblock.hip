@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64 * NW, WPC) void tailblock_kernel(const TailBlock
     // ordered by hand: lds_wait() before the first use of a batch, scheduling barriers around the users.
     const unsigned lds0 = (unsigned)(size_t)(tail_lds_cp)(smem);
     const unsigned lds_lane = lds0 + (unsigned)lane * 16u;
-    constexpr int BS = (MT == 1 && NTO == 28) ? 4 : (MT == 2 && NTO == 14) ? TAIL_BS224 : 7;   // weight fragments per prefetch batch (4 VGPRs each, two register sets)
+    constexpr int BS = (MT == 1 && NTO == 28) ? 4 : (MT >= 2 && NTO == 14) ? TAIL_BS224 : 7;   // weight fragments per prefetch batch (4 VGPRs each, two register sets)
     static_assert(NTO % BS == 0 && I::W1F % BS == 0 && I::FR == I::W1F + I::W2F, "batching assumes BS | NTO, BS | 2 KS");
 
     const int ngroups = (M + TPG - 1) / TPG;
@@ -910,7 +910,9 @@ int launch_tailblock(const TailBlockArgs& a, hipStream_t s) {
                          (reinterpret_cast<uintptr_t>(a.xn_next) & 7) == 0,
                      LSAM_ERR_BAD_ARG, "tailblock: next-LayerNorm output needs gamma, beta and ldn %% 4 == 0");
     switch (tail_variant(a.d)) {
-#ifdef TAIL_224_MT2
+#if defined(TAIL_224_MT4)
+        case 0: return launch_tail<7, 14, 4, 4, 1>(a, s);
+#elif defined(TAIL_224_MT2)
         case 0: return launch_tail<7, 14, 2, 4, 2>(a, s);
 #else
         case 0: return launch_tail<7, 14, 1, 8, 2>(a, s);    // 8 waves x 16 tokens: fits 2 waves per SIMD
