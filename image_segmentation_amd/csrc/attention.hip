@@ -216,8 +216,7 @@ __global__ void attn_fwd_kernel(const AttnArgs p, const float c_log2) {
                     s[t][r] = kidx < nk ? s[t][r] * c_log2 : -1.0e30f;
                     mx = fmaxf(mx, s[t][r]);
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = group4_max(mx);
             const float mnew = fmaxf(mrun[qt], mx);
             const float alpha = exp2f(mrun[qt] - mnew);
             mrun[qt] = mnew;
@@ -437,8 +436,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnArgs p, con
             float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
             for (int t = 1; t < 4; ++t) mx = fmaxf(fmaxf(mx, s[t][0]), fmaxf(fmaxf(s[t][1], s[t][2]), s[t][3]));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = group4_max(mx);
             const float mnew = fmaxf(mrun[qt], mx);
             if (__any(mnew != mrun[qt])) {
                 const float alpha = __builtin_amdgcn_exp2f((mrun[qt] - mnew) * c_log2);
@@ -638,8 +636,7 @@ __global__ __launch_bounds__(256) void attnw_fwd_kernel(const AttnArgs p, const 
         float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
         for (int t = 1; t < NKT; ++t) mx = fmaxf(fmaxf(mx, s[t][0]), fmaxf(fmaxf(s[t][1], s[t][2]), s[t][3]));
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = group4_max(mx);
         const float mneg = -mx * c_log2;
         float l = 0.f;
         bf16x8 pf[U];

@@ -164,6 +164,35 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // is not enough: hipcc does not count the LDS write of a DMA as something a workgroup release fence
 // has to wait for, and is free to place its vmcnt(0) AFTER the s_barrier (seen in the generated
 // code), which lets a wave read rows another wave's DMA has not landed yet.
+// Reductions over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48: the lanes that hold one token's
+// values in the MFMA D layout) on the VALU: v_permlane32_swap / v_permlane16_swap of a value with itself give
+// (x.lo, x.lo | x.hi, x.hi) and (r0, r0, r2, r2 | r1, r1, r3, r3), so op(a, b) is the xor-32 / xor-16 butterfly.
+// __shfl_xor compiles to ds_bpermute_b32: an LDS-pipe round trip with an lgkmcnt wait on the critical path of
+// every softmax row maximum.
+// Written as inline asm on two explicit copies: the instructions swap IN PLACE between two registers, and the
+// builtin form, given one value twice, was seen to hand back a single register for both results.  The s_nop
+// covers the VALU-write -> permlane-swap read hazard, which the compiler cannot see inside an asm statement.
+__device__ __forceinline__ void swap32_lanes(float& a, float& b) {   // a = (a.lo, b.lo), b = (a.hi, b.hi)
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap16_rows(float& a, float& b) {    // a = (a.r0, b.r0, a.r2, b.r2), b = (a.r1, b.r1, a.r3, b.r3)
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float group4_max(float x) {
+    float a = x, b = x;
+    swap32_lanes(a, b);
+    a = b = fmaxf(a, b);
+    swap16_rows(a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float group4_sum(float x) {
+    float a = x, b = x;
+    swap32_lanes(a, b);
+    a = b = a + b;
+    swap16_rows(a, b);
+    return a + b;
+}
+
 __device__ __forceinline__ void lds_dma_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

@@ -273,8 +273,7 @@ __global__ __launch_bounds__(256, 1) void winblock_attn_kernel(const WinBlockArg
                 float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
                 for (int jt = 1; jt < 4; ++jt) mx = fmaxf(fmaxf(mx, s[jt][0]), fmaxf(fmaxf(s[jt][1], s[jt][2]), s[jt][3]));
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = group4_max(mx);
                 const float mneg = -mx * p.c_log2;
                 float l = 0.f;
                 bf16x8 pf[2];
@@ -291,8 +290,7 @@ __global__ __launch_bounds__(256, 1) void winblock_attn_kernel(const WinBlockArg
                         }
                     pf[u] = f;
                 }
-                l += __shfl_xor(l, 16, 64);
-                l += __shfl_xor(l, 32, 64);
+                l = group4_sum(l);
                 const float inv = 1.0f / l;
                 f32x4 o[4];
 #pragma unroll
