@@ -290,8 +290,12 @@ typedef const __attribute__((address_space(1))) void* gbl_vp_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_p;
 __device__ uint4 g_attn_zero16 = {0u, 0u, 0u, 0u};
+__device__ uint4 g_attn_one16 = {0x00003F80u, 0u, 0u, 0u};   // bf16 1.0 followed by seven zeros
 
-template <int QT>
+// ONES (head_dim <= 56): the first padding channel of every valid key's V row is fed as 1.0 (its 16-byte chunk
+// is DMA'd from g_attn_one16 instead of the zero word), so channel hd of the output accumulates the softmax
+// denominator in the PV MFMAs: no per-element adds on the VALU, which is what bounds this kernel.
+template <int QT, bool ONES>
 __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnArgs p, const float c_log2) {
     using T = bf16;
     constexpr int KT2 = 64, RB = 128, TILE_B = KT2 * RB, STAGE = 2 * TILE_B, DT = 4;
@@ -376,6 +380,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnArgs p, con
                 const int part = (v ? 2 * dout : dout) + h * hd + dsrc;
                 const void* src = &g_attn_zero16;
                 if (kin) src = real ? static_cast<const void*>(qkv + tokoff + part) : static_cast<const void*>(bias_t + part);
+                if (ONES && v == 1 && dsrc == hd && kky[e] < G.wsh) src = &g_attn_one16;
                 const int j = wave + 4 * e + 8 * v;
                 __builtin_amdgcn_global_load_lds((gbl_vp_t)src, (lds_vp_t)(smem + buf * STAGE + j * 1024), 16, 0, 0);
             }
@@ -441,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnArgs p, con
             if (__any(mnew != mrun[qt])) {
                 const float alpha = __builtin_amdgcn_exp2f((mrun[qt] - mnew) * c_log2);
                 mrun[qt] = mnew;
-                lrun[qt] *= alpha;
+                if constexpr (!ONES) lrun[qt] *= alpha;
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
             }
@@ -456,11 +461,11 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnArgs p, con
                     for (int r = 0; r < 4; ++r) {
                         const float e = __builtin_amdgcn_exp2f(fmaf(s[2 * u + t][r], c_log2, mneg));
                         pv[t * 4 + r] = e;
-                        psum += e;
+                        if constexpr (!ONES) psum += e;
                     }
                 pf[qt][u] = frag_from_f<T>(pv);
             }
-            lrun[qt] += psum;
+            if constexpr (!ONES) lrun[qt] += psum;
         }
         // ---- O^T += V^T . P^T, V^T fragments by transposing LDS reads --------------------------
         // The reads are inline asm: hipcc cannot tell the builtin transposing read apart from the LDS
@@ -499,9 +504,18 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnArgs p, con
     T* __restrict__ out = static_cast<T*>(p.out);
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        float l = lrun[qt];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        float l;
+        if constexpr (ONES) {
+            // channel hd = tile hd / 16, lane group (hd % 16) / 4, element hd % 4 (hd % 8 == 0): owned by one lane per query
+            const int dt1 = hd >> 4, g1 = (hd & 15) >> 2;
+            float lv = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                if (dt == dt1) lv = o[qt][dt][0];
+            l = __shfl(lv, 16 * g1 + lr, 64);
+        } else {
+            l = group4_sum(lrun[qt]);
+        }
         if (qtok[qt] < 0) continue;
         const float inv = 1.0f / l;
 #pragma unroll
@@ -706,7 +720,8 @@ template <int QT> static int attn2_launch(const AttnArgs& a, int nqb, hipStream_
     const WinGeom G = make_geom(a.H, a.W, a.ws, a.pool);
     const float c = (1.0f / sqrtf((float)a.hd)) * 1.4426950408889634f;
     const dim3 grid(a.N * G.nwy * G.nwx, a.nh, nqb), blk(256);
-    hipLaunchKernelGGL((attn2_fwd_kernel<QT>), grid, blk, 0, s, a, c);
+    if (a.hd % 8 == 0 && a.hd <= 56) hipLaunchKernelGGL((attn2_fwd_kernel<QT, true>), grid, blk, 0, s, a, c);
+    else hipLaunchKernelGGL((attn2_fwd_kernel<QT, false>), grid, blk, 0, s, a, c);
     LSAM_LAUNCH_CHECK();
     return LSAM_OK;
 }
