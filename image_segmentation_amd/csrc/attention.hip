@@ -565,6 +565,7 @@ __global__ __launch_bounds__(256) void attnw_fwd_kernel(const AttnArgs p, const 
     const T* __restrict__ bias_t = static_cast<const T*>(p.bias_t);
     const size_t img_tok = (size_t)n * H * W;
 
+    const bool ones = hd % 8 == 0 && hd <= 56;   // kernel-uniform
     // ---- stage K and V: DMA instruction j covers tile rows 8j .. 8j+7 of K (j < NKP/8) or V --------
     {
         const int lrow = lane >> 3, dsrc = ((lane & 7) ^ lrow) * 8;   // swizzle applied on the source side
@@ -581,6 +582,8 @@ __global__ __launch_bounds__(256) void attnw_fwd_kernel(const AttnArgs p, const 
                 src = (y < H && x < W) ? static_cast<const void*>(qkv + (img_tok + (size_t)y * W + x) * p.ldqkv + part)
                                        : static_cast<const void*>(bias_t + part);
             }
+            // softmax denominator through the PV MFMAs: V's first padding channel of every valid key is 1.0
+            if (ones && v == 1 && kk < nk && dsrc == hd) src = &g_attn_one16;
             __builtin_amdgcn_global_load_lds((gbl_vp_t)src, (lds_vp_t)(smem + j * 1024), 16, 0, 0);
         }
     }
@@ -664,14 +667,12 @@ __global__ __launch_bounds__(256) void attnw_fwd_kernel(const AttnArgs p, const 
                     float e = 0.f;
                     if (2 * u + t < NKT) {
                         e = __builtin_amdgcn_exp2f(fmaf(s[2 * u + t < NKT ? 2 * u + t : 0][r], c_log2, mneg));
-                        l += e;
+                        if (!ones) l += e;
                     }
                     pv[t * 4 + r] = e;
                 }
             pf[u] = frag_from_f<T>(pv);
         }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
         // ---- O^T = V^T . P^T, V^T fragments by transposing LDS reads -------------------------------
         f32x4 o[DT];
 #pragma unroll
@@ -689,6 +690,15 @@ __global__ __launch_bounds__(256) void attnw_fwd_kernel(const AttnArgs p, const 
                 const uint2 u0 = __builtin_bit_cast(uint2, x0), u1 = __builtin_bit_cast(uint2, x1);
                 mma16(__builtin_bit_cast(bf16x8, make_uint4(u0.x, u0.y, u1.x, u1.y)), pf[u], o[dt]);
             }
+        if (ones) {   // channel hd of O^T: tile hd / 16, lane group (hd % 16) / 4, element 0
+            float lv = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                if (dt == (hd >> 4)) lv = o[dt][0];
+            l = __shfl(lv, 16 * ((hd & 15) >> 2) + lr, 64);
+        } else {
+            l = group4_sum(l);
+        }
         if (qtok >= 0) {
             const float inv = 1.0f / l;
 #pragma unroll
