@@ -178,6 +178,27 @@ __device__ __forceinline__ void swap32_lanes(float& a, float& b) {   // a = (a.l
 __device__ __forceinline__ void swap16_rows(float& a, float& b) {    // a = (a.r0, b.r0, a.r2, b.r2), b = (a.r1, b.r1, a.r3, b.r3)
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
+__device__ __forceinline__ void swap32_lanes(unsigned& a, unsigned& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap16_rows(unsigned& a, unsigned& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+// Two neighbouring 16-column tiles of the MFMA D layout (lane (g, lr): row lr, columns 16 nt + 4 g + r) as bf16:
+// regrouped across the four lanes of a row so that lane g holds the 8 consecutive columns 32 (nt/2) + 8 g .. + 7 and
+// stores them as ONE 16-byte word (64 contiguous bytes per row and instruction instead of 4 x 8).  Every lane of the
+// wave must call this (the swaps need all lanes); `ok` only guards the store.  rowp points at column 16 nt of the row.
+__device__ __forceinline__ void store_bf16_tile_pair(bf16* rowp, int g, const f32x4& v0, const f32x4& v1, bool ok) {
+    bf16x4 p0, p1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { p0[r] = (bf16)v0[r]; p1[r] = (bf16)v1[r]; }
+    uint2 x = __builtin_bit_cast(uint2, p0), y = __builtin_bit_cast(uint2, p1);
+    swap32_lanes(x.x, y.x);
+    swap32_lanes(x.y, y.y);
+    swap16_rows(x.x, y.x);
+    swap16_rows(x.y, y.y);
+    if (ok) *reinterpret_cast<uint4*>(rowp + 8 * g) = make_uint4(x.x, x.y, y.x, y.y);
+}
 __device__ __forceinline__ float group4_max(float x) {
     float a = x, b = x;
     swap32_lanes(a, b);

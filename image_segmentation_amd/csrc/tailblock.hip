@@ -409,14 +409,18 @@ __global__ __launch_bounds__(64 * NW, WPC) void tailblock_kernel(const TailBlock
                 q += __shfl_xor(q, 32, 64);
                 const float rstd = 1.0f / sqrtf(q * inv_d + p.eps);
                 const int m = m0 + mt * 16 + lr;
+                static_assert(NTO % 2 == 0, "bf16 rows are stored as pairs of column tiles");
 #pragma unroll
-                for (int nt = 0; nt < NTO; ++nt) {
-                    const int c0 = 16 * nt + 4 * g;
-                    const f32x4 gm = load4(p.gamma_n + c0), bt = load4(p.beta_n + c0);
-                    f32x4 v;
+                for (int nt = 0; nt < NTO; nt += 2) {
+                    f32x4 v[2];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaf((acc[mt][nt][r] - mean) * rstd, gm[r], bt[r]);
-                    if (m < M) store4(xo + (size_t)m * p.ldn + c0, v);
+                    for (int t = 0; t < 2; ++t) {
+                        const int c0 = 16 * (nt + t) + 4 * g;
+                        const f32x4 gm = load4(p.gamma_n + c0), bt = load4(p.beta_n + c0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[t][r] = fmaf((acc[mt][nt + t][r] - mean) * rstd, gm[r], bt[r]);
+                    }
+                    store_bf16_tile_pair(xo + (size_t)min(m, M - 1) * p.ldn + 16 * nt, g, v[0], v[1], m < M);
                 }
             }
         }
@@ -452,7 +456,7 @@ template <int KS, int NTO> struct PairImg {
     static constexpr int NPC = KS / 2;              // proj chunks: two k-steps of all row tiles
     static constexpr int FR = 2 * NTO;              // fragments per chunk; wave half hh owns [hh FR/2, (hh+1) FR/2)
     static constexpr int HF = FR / 2;               //   proj: [kl][ntl]; MLP: fc1 [ksl][t] (2 KSH), then fc2 [ntl] (NTH)
-    static constexpr int B1_OFF = FR * 1024;        // fc1 biases of the chunk whose GELU runs in this iteration
+    static constexpr int B1_OFF = FR * 1024;        // fc1 biases of the chunk (they seed the fc1 accumulators)
     static constexpr int CHUNK_B = (FR + 1) * 1024;
     static constexpr int VEC = 16 * NTO;
     static constexpr int XCH_OFF = 2 * CHUNK_B;     // exchange: [2 parities]{fc1 partials [8 waves][1 KiB], GELU halves [8 waves][1 KiB]}
@@ -497,7 +501,7 @@ __global__ void pack_tailpair_kernel(const float* __restrict__ wproj, const floa
         reinterpret_cast<bf16*>(img)[i] = (bf16)v;
     }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nck * 256; i += gridDim.x * blockDim.x) {
-        const int ck = i / 256, e = i % 256, c = ck - I::NPC - 1;   // biases of the chunk GELU'd in iteration c + 1
+        const int ck = i / 256, e = i % 256, c = ck - I::NPC;   // biases of the chunk whose fc1 runs in this iteration
         const bool ok = c >= 0 && c < nch && e < 32;
         reinterpret_cast<float*>(img + (size_t)ck * I::CHUNK_B + I::B1_OFF)[e] = ok ? b1[32 * c + e] : 0.f;
     }
@@ -710,13 +714,11 @@ __global__ __launch_bounds__(512) void tailpair_kernel(const TailBlockArgs p) {
             static_assert(BG0 + BGN < NB && BPW < NB && 8 % BGN == 0, "schedule");
             bf16x8 w[2][BS];
             f32x4 part[MT][2];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) part[mt][0] = part[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             bf16x8 pp, hq, hnew, hfull[MT];
             f32x4 bi;
             lds_frags<0, BS>(base, w[0]);
             pp = lds_read_b128(xr);           // partner's partial of MY tile, chunk c - 1: [mt][r] bf16
-            bi = lds_f32x4(baddr);            // fc1 biases of my tile, chunk c - 1
+            bi = lds_f32x4(baddr);            // fc1 biases of my tile, chunk c: the accumulators of my tile start there
             hq = lds_read_b128(xr + 8192);    // partner's GELU half of chunk c - 2
             static_for<0, NB>([&](auto b_) {
                 constexpr int b = decltype(b_)::value;
@@ -736,7 +738,7 @@ __global__ __launch_bounds__(512) void tailpair_kernel(const TailBlockArgs p) {
                 if constexpr (b >= BG0 && b < BG0 + BGN) {   // GELU of chunk c - 1, my tile
 #pragma unroll
                     for (int e = (8 / BGN) * (b - BG0); e < (8 / BGN) * (b - BG0 + 1); ++e) {
-                        float x = (own[e >> 2][e & 3] + (float)pp[e]) + bi[e & 3];
+                        float x = own[e >> 2][e & 3] + (float)pp[e];
 #if !(TAIL_ABL & 4)
                         x = gelu_t<true>(x);
 #endif
@@ -754,10 +756,13 @@ __global__ __launch_bounds__(512) void tailpair_kernel(const TailBlockArgs p) {
 #pragma unroll
                 for (int i = 0; i < BS; ++i) {
                     const int fl = b * BS + i;
-                    if (fl < F1) {   // fc1 partial: fragment [ksl][tile], tile 0 = mine
+                    if (fl < F1) {   // fc1 partial: fragment [ksl][tile], tile 0 = mine (seeded with the bias)
                         const int ksl = fl >> 1, t = fl & 1;
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) mma16(w[b & 1][i], xn[mt][ksl], part[mt][t]);
+                        for (int mt = 0; mt < MT; ++mt) {
+                            if (ksl == 0) part[mt][t] = t == 0 ? bi : f32x4{0.f, 0.f, 0.f, 0.f};
+                            mma16(w[b & 1][i], xn[mt][ksl], part[mt][t]);
+                        }
                     } else {         // fc2 of chunk c - 2
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) mma16(w[b & 1][i], hfull[mt], acc[mt][fl - F1]);
@@ -792,14 +797,18 @@ __global__ __launch_bounds__(512) void tailpair_kernel(const TailBlockArgs p) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int m = m0 + mt * 16 + lr;
+                static_assert(NTH % 2 == 0, "bf16 rows are stored as pairs of column tiles");
 #pragma unroll
-                for (int nt = 0; nt < NTH; ++nt) {
-                    const int c0 = cbase0 + 16 * nt;
-                    const f32x4 gm = load4(p.gamma_n + c0), bt = load4(p.beta_n + c0);
-                    f32x4 v;
+                for (int nt = 0; nt < NTH; nt += 2) {
+                    f32x4 v[2];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaf((acc[mt][nt][r] - mean[mt]) * rstd[mt], gm[r], bt[r]);
-                    if (m < M) store4(xo + (size_t)m * p.ldn + c0, v);
+                    for (int t = 0; t < 2; ++t) {
+                        const int c0 = cbase0 + 16 * (nt + t);
+                        const f32x4 gm = load4(p.gamma_n + c0), bt = load4(p.beta_n + c0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[t][r] = fmaf((acc[mt][nt + t][r] - mean[mt]) * rstd[mt], gm[r], bt[r]);
+                    }
+                    store_bf16_tile_pair(xo + (size_t)min(m, M - 1) * p.ldn + 16 * NTH * hh + 16 * nt, g, v[0], v[1], m < M);
                 }
             }
         }
@@ -906,9 +915,9 @@ int launch_tailblock(const TailBlockArgs& a, hipStream_t s) {
     LSAM_REQUIRE(aligned16(a.a) && aligned16(a.res) && aligned16(a.out) && aligned16(a.img) && aligned16(a.vec),
                  LSAM_ERR_BAD_ARG, "tailblock: pointers must be 16-byte aligned");
     if (a.xn_next)
-        LSAM_REQUIRE(a.gamma_n && a.beta_n && a.ldn >= a.d && a.ldn % 4 == 0 && aligned16(a.gamma_n) && aligned16(a.beta_n) &&
-                         (reinterpret_cast<uintptr_t>(a.xn_next) & 7) == 0,
-                     LSAM_ERR_BAD_ARG, "tailblock: next-LayerNorm output needs gamma, beta and ldn %% 4 == 0");
+        LSAM_REQUIRE(a.gamma_n && a.beta_n && a.ldn >= a.d && a.ldn % 8 == 0 && aligned16(a.gamma_n) && aligned16(a.beta_n) &&
+                         aligned16(a.xn_next),
+                     LSAM_ERR_BAD_ARG, "tailblock: next-LayerNorm output needs gamma, beta, 16-byte alignment and ldn %% 8 == 0");
     switch (tail_variant(a.d)) {
 #if defined(TAIL_224_MT4)
         case 0: return launch_tail<7, 14, 4, 4, 1>(a, s);
