@@ -206,8 +206,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlpblock_kernel(cons
                 const unsigned sw0 = lr * 128 + ((g ^ (lr & 7)) << 4), sw1 = lr * 128 + (((4 + g) ^ (lr & 7)) << 4);
                 const unsigned a0 = cb + sw0, a1 = cb + sw1, ab = cb + I::B1_OFF + g * 16;
                 bf16x8 wa[8], wb[8], w2f[2 * NTO];
-                f32x4 acc1[MT][4];
-                mlp_static_for<0, 4>([&](auto nt_) { mlp_rd<decltype(nt_)::value * 64>(ab, acc1[0][decltype(nt_)::value]); });
+                f32x4 acc1[MT][4], bi[4];   // the chunk's fc1 biases are the C operand of each tile's first MFMA
+                mlp_static_for<0, 4>([&](auto nt_) { mlp_rd<decltype(nt_)::value * 64>(ab, bi[decltype(nt_)::value]); });
                 mlp_static_for<0, 8>([&](auto i_) {   // k-steps 0, 1
                     constexpr int i = decltype(i_)::value, ks = i >> 2, nt = i & 3;
                     mlp_rd<(ks >> 1) * 8192 + nt * 2048>((ks & 1) ? a1 : a0, wa[i]);
@@ -220,13 +220,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlpblock_kernel(cons
                 });
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                    for (int mt = 1; mt < MT; ++mt) acc1[mt][nt] = acc1[0][nt];
-#pragma unroll
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) mma16(wa[i], xn[mt][i >> 2], acc1[mt][i & 3]);
+                    for (int mt = 0; mt < MT; ++mt) {
+                        if (i < 4) acc1[mt][i] = bi[i];
+                        mma16(wa[i], xn[mt][i >> 2], acc1[mt][i & 3]);
+                    }
                 __builtin_amdgcn_sched_barrier(0);
                 mlp_lds_wait();
                 mlp_static_for<0, 2 * NTO>([&](auto i_) {   // all fc2 fragments of the chunk: they land under the GELU
