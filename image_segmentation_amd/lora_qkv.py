@@ -151,3 +151,62 @@ def custom_load_lora_parameters(model, load_path):
     for name in err.missing_keys:
         if any(s in name for s in ("_a_q", "A_q", "_b_q", "B_q")):
             raise ValueError(f"Custom LoRA Missing key in state_dict: {name}")
+
+
+class LoRABank:
+    """In-memory sets of LoRA factors, switched without touching the file system.
+
+    The reference's continual-learning loop runs the previous domain's LoRA as a distillation teacher by
+    saving the current factors to disk, loading the previous ones, running the model, and loading the current
+    ones back -- per batch, with five barriers around the files (train_cl.py:209-228), and its nearest-domain
+    selection loads one LoRA file per candidate domain (train_cl_kmean.py:189-207).  Here every set stays
+    resident on the device; `activate` is eight small device-to-device copies into the module's LoRA
+    parameters, and the next forward re-packs only the LoRA-dependent slices of the packed weights
+    (lsam_hiera_pack_lora), so a teacher pass costs one forward and no I/O.  All factors are kept, q and v
+    (the reference's files hold only the q factors, see custom_save_lora_parameters)."""
+
+    _KEYS = ("linear_a_q", "linear_b_q", "linear_a_v", "linear_b_v", "A_q", "B_q", "A_v", "B_v")
+
+    def __init__(self, model: nn.Module):
+        self._params = {n: p for n, p in model.named_parameters() if any(k in n for k in self._KEYS)}
+        if not self._params:
+            raise ValueError("LoRABank: the model has no LoRA parameters (wrap_image_encoder_lora first)")
+        self._sets = {}
+
+    def keys(self):
+        return list(self._sets)
+
+    def __contains__(self, key) -> bool:
+        return key in self._sets
+
+    @torch.no_grad()
+    def store(self, key) -> None:
+        """Snapshot the model's current LoRA factors under `key` (overwrites an existing set in place)."""
+        old = self._sets.get(key)
+        if old is not None:
+            for n, p in self._params.items():
+                old[n].copy_(p)
+        else:
+            self._sets[key] = {n: p.detach().clone() for n, p in self._params.items()}
+
+    @torch.no_grad()
+    def activate(self, key) -> None:
+        """Make set `key` the model's LoRA factors (the parameters keep their identity, optimizer state and
+        requires_grad; only their values change)."""
+        if key not in self._sets:
+            raise KeyError(f"LoRABank: no set {key!r} (have {self.keys()})")
+        for n, p in self._params.items():
+            p.copy_(self._sets[key][n])
+
+    def state_dict(self, key):
+        """The stored set as a state_dict fragment (load with model.load_state_dict(..., strict=False))."""
+        return {n: t.clone() for n, t in self._sets[key].items()}
+
+    def load_state_dict(self, key, sd) -> None:
+        """Add a set from a (possibly q-only, reference-format) LoRA state_dict; missing v factors keep the
+        model's current values, as custom_load_lora_parameters would leave them."""
+        cur = {n: p.detach().clone() for n, p in self._params.items()}
+        for n, t in sd.items():
+            if n in cur:
+                cur[n].copy_(t.to(cur[n].device, cur[n].dtype))
+        self._sets[key] = cur

@@ -129,3 +129,48 @@ def test_lora_save_format_matches_reference_filter(tmp_path):
     m.custom_save_lora_parameters(enc, f, include_v=True)
     assert len(torch.load(f, weights_only=True)) == 8
     m.custom_load_lora_parameters(enc, f)
+
+
+def test_lora_bank_switches_sets_in_memory(tmp_path):
+    """LoRABank: the in-memory replacement of the save -> load -> forward -> load sequence of the reference's
+    distillation teacher pass (train_cl.py:209-228).  Host logic only: values, identity of the parameters,
+    independence of the stored sets, and interchange with the reference's q-only file format."""
+    import image_segmentation_amd as m
+    enc = m.build_image_encoder(dict(TINY))
+    m.wrap_image_encoder_lora(types.SimpleNamespace(image_encoder=enc), 4)
+    lora = {n: p for n, p in enc.named_parameters() if "linear_a_" in n or "linear_b_" in n}
+    assert len(lora) == 8
+    bank = m.LoRABank(enc)
+    with torch.no_grad():
+        for i, p in enumerate(lora.values()):
+            p.fill_(1.0 + i)
+    bank.store("domain0")
+    with torch.no_grad():
+        for p in lora.values():
+            p.mul_(-2.0)
+    bank.store("domain1")
+    ids = {n: id(p) for n, p in lora.items()}
+    bank.activate("domain0")
+    assert all(torch.all(p == 1.0 + i) for i, p in enumerate(lora.values()))
+    bank.activate("domain1")
+    assert all(torch.all(p == -2.0 * (1.0 + i)) for i, p in enumerate(lora.values()))
+    assert {n: id(p) for n, p in enc.named_parameters() if n in ids} == ids      # same Parameter objects
+    with torch.no_grad():
+        next(iter(lora.values())).zero_()                                          # training moves on ...
+    bank.activate("domain1")
+    assert torch.all(next(iter(lora.values())) == -2.0)                            # ... the stored set did not
+    assert sorted(bank.keys()) == ["domain0", "domain1"] and "domain0" in bank
+    with pytest.raises(KeyError):
+        bank.activate("nope")
+    # a reference-format file (q factors only) becomes a set; v factors keep the model's current values
+    f = tmp_path / "lora_q.pt"
+    bank.activate("domain0")
+    m.custom_save_lora_parameters(enc, f)
+    bank.activate("domain1")
+    bank.load_state_dict("from_file", torch.load(f, weights_only=True))
+    bank.activate("from_file")
+    for i, (n, p) in enumerate(lora.items()):
+        want = 1.0 + i if ("_a_q" in n or "_b_q" in n) else -2.0 * (1.0 + i)
+        assert torch.all(p == want), n
+    with pytest.raises(ValueError):
+        m.LoRABank(m.build_image_encoder(dict(TINY)))

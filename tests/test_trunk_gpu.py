@@ -263,3 +263,31 @@ def test_large_family_backward_is_rejected_loudly():
     with pytest.raises((LsamError, RuntimeError)):
         fpn_loss(enc(img)).backward()
         torch.cuda.synchronize()
+
+
+def test_lora_bank_teacher_pass_matches_a_model_built_with_those_factors():
+    """The distillation-teacher pass of train_cl.py:209-228 without files: after LoRABank.activate(prev) the
+    encoder must produce exactly what an encoder built with the previous domain's factors produces, and
+    after activate(curr) exactly its own output again (the packed LoRA slices follow the parameters)."""
+    import image_segmentation_amd as m
+    from image_segmentation_amd.synth import synth_frames
+    img = synth_frames(2, 256, 0, device="cuda")
+    enc = make_encoder(TINY, seed=0)
+    ref_prev = make_encoder(TINY, seed=0)
+    with torch.no_grad():
+        for name, p in ref_prev.named_parameters():   # "previous domain": same frozen weights, other LoRA factors
+            if "linear_a_" in name or "linear_b_" in name:
+                p.mul_(-0.5).add_(0.01)
+    bank = m.LoRABank(enc)
+    bank.store("curr")
+    bank.load_state_dict("prev", {n: p.detach() for n, p in ref_prev.named_parameters()
+                                  if "linear_a_" in n or "linear_b_" in n})
+    with torch.no_grad():
+        own = enc(img)["vision_features"].clone()
+        want = ref_prev(img)["vision_features"]
+        assert rel_err(own, want) > 1e-3                     # the two LoRA sets really differ at the output
+        bank.activate("prev")
+        got = enc(img)["vision_features"].clone()
+        assert torch.equal(got, want)
+        bank.activate("curr")
+        assert torch.equal(enc(img)["vision_features"], own)
