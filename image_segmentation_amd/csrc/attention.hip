@@ -43,6 +43,35 @@ template <typename T> __device__ __forceinline__ typename Tr<T>::frag frag_from_
     return f;
 }
 
+// The 2x2 max-pool of q (do_pool on the q part of qkv, hieradet.py:63-67) for 8 channels of one pooled query: the
+// four source rows are requested TOGETHER (clamped addresses, out-of-grid positions replaced by the pad token's
+// q = bias afterwards).  Written as a loop over the pool window, each load waited for its own round trip before
+// the next was issued: four dependent HBM latencies per k-step in front of every small-window workgroup.
+template <typename T, typename BiasLoad>
+__device__ __forceinline__ void load_q_pool2(const T* __restrict__ qkv, size_t img_tok, int ldqkv, int H, int W, int y0, int x0,
+                                             int col, BiasLoad&& bias8, float* v) {
+    float t[4][8];
+    bool in[4];
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab) {
+        const int y = y0 + (ab >> 1), x = x0 + (ab & 1);
+        in[ab] = y < H && x < W;
+        load8f<T>(qkv + (img_tok + (size_t)min(y, H - 1) * W + min(x, W - 1)) * ldqkv + col, t[ab]);
+    }
+    if (!(in[0] && in[1] && in[2] && in[3])) {   // rare: only windows that hang over the grid
+        float b[8];
+        bias8(b);
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab)
+            if (!in[ab]) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[ab][j] = b[j];
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaxf(t[0][j], t[1][j]), fmaxf(t[2][j], t[3][j]));
+}
+
 struct WinGeom {
     int wsh, wsw, nwy, nwx;   // window size (rows, cols) on the input grid, windows per image
     int qh, qw, Ho, Wo;       // query window size and output grid
@@ -118,6 +147,12 @@ __global__ void attn_fwd_kernel(const AttnArgs p, const float c_log2) {
                 if (p.pool == 1) {
                     const size_t tok = img_tok + (size_t)(wy * G.wsh + iy) * W + (wx * G.wsw + ix);
                     load8f<T>(qkv + tok * p.ldqkv + h * hd + d0, v);
+                } else if (p.pool == 2) {
+                    load_q_pool2<T>(qkv, img_tok, p.ldqkv, H, W, wy * G.wsh + iy * 2, wx * G.wsw + ix * 2, h * hd + d0,
+                                    [&](float* b) {
+#pragma unroll
+                                        for (int j = 0; j < 8; ++j) b[j] = to_f(from_f<T>(bias[h * hd + d0 + j]));
+                                    }, v);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = -3.0e38f;
@@ -337,6 +372,9 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnArgs p, con
                 if (p.pool == 1) {
                     const size_t tok = img_tok + (size_t)(wy * G.wsh + iy) * W + (wx * G.wsw + ix);
                     load8f<T>(qkv + tok * p.ldqkv + h * hd + d0, v);
+                } else if (p.pool == 2) {
+                    load_q_pool2<T>(qkv, img_tok, p.ldqkv, H, W, wy * G.wsh + iy * 2, wx * G.wsw + ix * 2, h * hd + d0,
+                                    [&](float* b) { load8f<T>(bias_t + h * hd + d0, b); }, v);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = -3.0e38f;
@@ -607,6 +645,9 @@ __global__ __launch_bounds__(256) void attnw_fwd_kernel(const AttnArgs p, const 
                 if (p.pool == 1) {
                     const size_t tok = img_tok + (size_t)(wy * G.wsh + iy) * W + (wx * G.wsw + ix);
                     load8f<T>(qkv + tok * p.ldqkv + h * hd + d0, v);
+                } else if (p.pool == 2) {
+                    load_q_pool2<T>(qkv, img_tok, p.ldqkv, H, W, wy * G.wsh + iy * 2, wx * G.wsw + ix * 2, h * hd + d0,
+                                    [&](float* b) { load8f<T>(bias_t + h * hd + d0, b); }, v);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = -3.0e38f;
