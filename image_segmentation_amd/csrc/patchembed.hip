@@ -69,12 +69,18 @@ __global__ __launch_bounds__(256, 2) void patch_embed_kernel(const float* __rest
         const int n = t / (tiles_x * tiles_y), tr = t % (tiles_x * tiles_y);
         const int oy0 = (tr / tiles_x) * PE_TY, ox0 = (tr % tiles_x) * PE_TX;
         const int iy0 = 4 * oy0 - 3, ix0 = 4 * ox0 - 3;
-        __syncthreads();   // every wave is done with the previous tile (and the weight copy is visible)
-        for (int i = tid; i < 3 * PE_R * PE_C4; i += 256) {
+        // all of this thread's input words are requested before any is used (one memory round trip per tile, not one
+        // per loop iteration), and before the barrier that frees the LDS tile: they overlap the tail of the other waves'
+        // compute on the previous tile
+        constexpr int NLD = (3 * PE_R * PE_C4 + 255) / 256;
+        f32x4 ld[NLD];
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int i = tid + 256 * it;
             const int c4 = i % PE_C4, rr = i / PE_C4, r = rr % PE_R, c = rr / PE_R;
             const int iy = iy0 + r, ix = ix0 + 4 * c4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (iy >= 0 && iy < S) {
+            if (i < 3 * PE_R * PE_C4 && iy >= 0 && iy < S) {
                 const float* row = frames + (((size_t)n * 3 + c) * S + iy) * S;
                 if (ix >= 0 && ix + 3 < S) {
                     // 4-byte aligned 16-byte load (ix = 4 ox0 - 3 + 4 c4): dword alignment is all the hardware needs
@@ -85,9 +91,18 @@ __global__ __launch_bounds__(256, 2) void patch_embed_kernel(const float* __rest
                         if (ix + e >= 0 && ix + e < S) v[e] = row[ix + e];
                 }
             }
-            bf16x4 o;
-            o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
-            *reinterpret_cast<bf16x4*>(tile + (c * PE_R + r) * PE_PITCH + 4 * c4) = o;
+            ld[it] = v;
+        }
+        __syncthreads();   // every wave is done with the previous tile (and the weight copy is visible)
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int i = tid + 256 * it;
+            if (i < 3 * PE_R * PE_C4) {
+                const int c4 = i % PE_C4, rr = i / PE_C4;   // rr = c * PE_R + r
+                bf16x4 o;
+                o[0] = (bf16)ld[it][0]; o[1] = (bf16)ld[it][1]; o[2] = (bf16)ld[it][2]; o[3] = (bf16)ld[it][3];
+                *reinterpret_cast<bf16x4*>(tile + rr * PE_PITCH + 4 * c4) = o;
+            }
         }
         __syncthreads();
 
