@@ -189,6 +189,51 @@ __global__ void attn_fwd_kernel(const AttnArgs p, const float c_log2) {
     for (int tile = 0; tile < ntiles; ++tile) {
         __syncthreads();
         // ---- stage K (row-major, swizzled) and V (transposed) --------------------------------
+        if constexpr (NWH > 1 && sizeof(T) == 2) {
+            // head-packed small windows: the wave stages its own tile in exactly KT CPR / 64 rounds; all rounds'
+            // global loads are requested before the first LDS store (clamped addresses; pad tokens and the
+            // slots past nk / hd are patched afterwards), one memory round trip per tile instead of one per round
+            constexpr int NIT = KT * CPR / 64;
+            uint4 kvr[NIT], vvr[NIT];
+            bool use[NIT], real[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = tid + 64 * it;
+                const int key = i / CPR, ch = i % CPR, d0 = ch * EPC;
+                const int kk = tile * KT + key;
+                const int ky = kk / G.wsw, kx = kk % G.wsw;
+                const int y = wy * G.wsh + ky, x = wx * G.wsw + kx;
+                use[it] = kk < nk && d0 < hd;
+                real[it] = y < H && x < W;
+                const T* src = qkv + (img_tok + (size_t)min(y, H - 1) * W + min(x, W - 1)) * p.ldqkv + dout + h * hd + min(d0, hd - EPC);
+                kvr[it] = *reinterpret_cast<const uint4*>(src);
+                vvr[it] = *reinterpret_cast<const uint4*>(src + dout);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = tid + 64 * it;
+                const int key = i / CPR, ch = i % CPR, d0 = ch * EPC;
+                uint4 kv = kvr[it], vv = vvr[it];
+                if (!use[it]) {
+                    kv = make_uint4(0, 0, 0, 0);
+                    vv = kv;
+                } else if (!real[it]) {   // zero-pad token: k, v = bias
+                    T kt_[EPC], vt2[EPC];
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        kt_[e] = from_f<T>(bias[dout + h * hd + d0 + e]);
+                        vt2[e] = from_f<T>(bias[2 * dout + h * hd + d0 + e]);
+                    }
+                    kv = *reinterpret_cast<const uint4*>(kt_);
+                    vv = *reinterpret_cast<const uint4*>(vt2);
+                }
+                *reinterpret_cast<uint4*>(ks_ + key * RB + (swz(key, ch) << 4)) = kv;
+                const T* ve = reinterpret_cast<const T*>(&vv);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e)
+                    *reinterpret_cast<T*>(vt_ + (d0 + e) * VRB + key * (int)sizeof(T)) = ve[e];
+            }
+        } else
         for (int i = tid; i < KT * CPR; i += nthr) {
             const int key = i / CPR, ch = i % CPR, d0 = ch * EPC;
             const int kk = tile * KT + key;
