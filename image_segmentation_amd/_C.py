@@ -103,6 +103,7 @@ def lib() -> C.CDLL:
         L.lsam_window_block_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, f, vp]
         L.lsam_mlp_block_pack.argtypes = [vp, vp, vp, vp, i, vp, vp, vp]
         L.lsam_mlp_block_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i, i, f, vp]
+        L.lsam_mlp_block_fwd_next_norm.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, vp, vp, i, i, f, vp]
         L.lsam_prof_arm.argtypes = [i]
         L.lsam_prof_read.argtypes = [i, vp, vp, vp, vp]
         _lib = L
@@ -141,5 +142,5 @@ EXPORTED = [
     "lsam_window_block_fwd", "lsam_mlp_block_image_bytes", "lsam_mlp_block_bias_floats", "lsam_mlp_block_pack",
     "lsam_mlp_block_fwd", "lsam_tail_block_image_bytes", "lsam_tail_block_vec_floats", "lsam_tail_block_pack",
     "lsam_tail_block_fwd", "lsam_patch_embed_image_bytes", "lsam_patch_embed_pack", "lsam_patch_embed_fwd", "lsam_linear_maxpool2x2",
-    "lsam_lateral_conv_image_bytes", "lsam_lateral_conv_pack", "lsam_lateral_conv_fwd",
+    "lsam_lateral_conv_image_bytes", "lsam_lateral_conv_pack", "lsam_lateral_conv_fwd", "lsam_mlp_block_fwd_next_norm",
 ]

@@ -156,6 +156,19 @@ int lsam_mlp_block_fwd(const float* x, float* y, const float* norm2_w, const flo
     return launch_mlpblock(a, static_cast<hipStream_t>(stream));
 }
 
+int lsam_mlp_block_fwd_next_norm(const float* x, float* y, const float* norm2_w, const float* norm2_b, const void* image,
+                                 const float* bias_table, void* xn_next, int ldn, const float* next_norm_w,
+                                 const float* next_norm_b, int M, int d, float eps, lsam_stream_t stream) {
+    LSAM_REQUIRE(mlpblock_supported(d), LSAM_ERR_UNSUPPORTED, "mlp_block: width %d not supported", d);
+    LSAM_REQUIRE(xn_next, LSAM_ERR_BAD_ARG, "mlp_block_fwd_next_norm: xn_next is null");
+    MlpBlockArgs a{x, y, norm2_w, norm2_b, image, bias_table, M, d, mlpblock_chunks(d), eps};
+    a.xn_next = xn_next;
+    a.ldn = ldn;
+    a.gamma_n = next_norm_w;
+    a.beta_n = next_norm_b;
+    return launch_mlpblock(a, static_cast<hipStream_t>(stream));
+}
+
 size_t lsam_tail_block_image_bytes(int d) { return tailblock_supported(d) ? tailblock_image_bytes(d) : 0; }
 size_t lsam_tail_block_vec_floats(int d) { return tailblock_supported(d) ? tailblock_vec_floats(d) : 0; }
 int lsam_tail_block_pack(const float* proj_w, const float* proj_b, const float* norm2_w, const float* norm2_b,

@@ -351,7 +351,16 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
         if (g.fused_mlp) {   // one kernel, in place on the residual stream
             MlpBlockArgs ma{y, y, at<float>(arena, o.ln2w), at<float>(arena, o.ln2b), at<char>(arena, o.mimg),
                             at<float>(arena, o.mbias), Mo, q, mlpblock_chunks(q), 1e-6f};
+            // the next block's norm1 from the same registers when that block starts with a plain LayerNorm
+            const bool next_ln = !last && !h->blk[i + 1].fused_attn && !h->blk[i + 1].lora && h->blk[i + 1].dim == q;
+            if (next_ln) {
+                ma.xn_next = at<T>(ws, w.xn);
+                ma.ldn = h->blk[i + 1].kq;
+                ma.gamma_n = at<float>(arena, h->off[i + 1].ln1w);
+                ma.beta_n = at<float>(arena, h->off[i + 1].ln1b);
+            }
             LSAM_TRY(launch_mlpblock(ma, s));
+            xn_ready = next_ln;
             x = y;
         } else {
         T* yn = at<T>(ws, w.xn);

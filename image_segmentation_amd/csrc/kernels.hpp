@@ -102,6 +102,8 @@ struct MlpBlockArgs {
     const float* bias_p;  // fc1 bias padded to 64 * nch, then fc2 bias
     int M, d, nch;
     float eps;
+    // optional: LayerNorm of the block's OUTPUT with the next block's norm1 parameters, T = bf16 [M][ldn]
+    void* xn_next = nullptr; int ldn = 0; const float* gamma_n = nullptr; const float* beta_n = nullptr;
 };
 bool mlpblock_supported(int d);
 int mlpblock_chunks(int d);

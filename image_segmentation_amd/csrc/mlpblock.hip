@@ -324,6 +324,42 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlpblock_kernel(cons
                 }
             }
         }
+        // ---- optional LayerNorm 1 of the next block, from the same registers (hieradet.py:136) --------------
+        if (p.xn_next) {   // kernel-uniform
+            bf16* __restrict__ xo = static_cast<bf16*>(p.xn_next);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt)
+                    if (16 * nt + 4 * g < d) sacc += (acc2[mt][nt][0] + acc2[mt][nt][1]) + (acc2[mt][nt][2] + acc2[mt][nt][3]);
+                const float mean = group4_sum(sacc) / (float)d;
+                float q = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt)
+                    if (16 * nt + 4 * g < d) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float dd = acc2[mt][nt][r] - mean;
+                            q += dd * dd;
+                        }
+                    }
+                const float rstd = 1.0f / sqrtf(group4_sum(q) / (float)d + p.eps);
+                const int m = m0 + mt * 16 + lr;
+                bf16* rowp = xo + (size_t)min(m, M - 1) * p.ldn;
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt) {
+                    const int c0 = 16 * nt + 4 * g;
+                    if (c0 < d && m < M) {
+                        const f32x4 gm = load4(p.gamma_n + c0), bt = load4(p.beta_n + c0);
+                        f32x4 v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = (acc2[mt][nt][r] - mean) * rstd * gm[r] + bt[r];
+                        store4(rowp + c0, v);
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -384,6 +420,10 @@ int launch_mlpblock(const MlpBlockArgs& a, hipStream_t s) {
     LSAM_REQUIRE(a.M > 0 && a.nch == mlpblock_chunks(a.d), LSAM_ERR_BAD_ARG, "mlpblock: bad shape");
     LSAM_REQUIRE(aligned16(a.x) && aligned16(a.y) && aligned16(a.img) && aligned16(a.gamma) && aligned16(a.beta) &&
                      aligned16(a.bias_p), LSAM_ERR_BAD_ARG, "mlpblock: pointers must be 16-byte aligned");
+    if (a.xn_next)
+        LSAM_REQUIRE(a.gamma_n && a.beta_n && a.ldn >= a.d && a.ldn % 4 == 0 && aligned16(a.gamma_n) && aligned16(a.beta_n) &&
+                         (reinterpret_cast<uintptr_t>(a.xn_next) & 7) == 0,
+                     LSAM_ERR_BAD_ARG, "mlpblock: next-LayerNorm output needs gamma, beta, 8-byte alignment and ldn %% 4 == 0");
     switch (mlp_variant(a.d)) {
         case 0: return launch_mlp<2, 4, 2, 4>(a, s);
         case 1: return launch_mlp<4, 7, 2, 4>(a, s);

@@ -236,6 +236,18 @@ def mlp_block_fwd(x, norm2_w, norm2_b, img, bias, eps: float = 1e-6, out=None):
     return y
 
 
+def mlp_block_fwd_next_norm(x, norm2_w, norm2_b, img, bias, next_norm_w, next_norm_b, eps: float = 1e-6):
+    """(y, LayerNorm_next(y) as bf16): lsam_mlp_block_fwd plus the following block's norm1 from the same registers."""
+    _need_gpu(x, norm2_w, norm2_b, img, bias, next_norm_w, next_norm_b)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+    M, d = x.shape
+    y = torch.empty_like(x)
+    xn = torch.empty(M, d, dtype=torch.bfloat16, device=x.device)
+    check(lib().lsam_mlp_block_fwd_next_norm(ptr(x), ptr(y), ptr(norm2_w), ptr(norm2_b), ptr(img), ptr(bias), ptr(xn), d,
+                                             ptr(next_norm_w), ptr(next_norm_b), M, d, eps, stream()))
+    return y, xn
+
+
 def lateral_conv_supported(in_channels: int, out_channels: int) -> bool:
     return lib().lsam_lateral_conv_image_bytes(in_channels, out_channels) > 0
 

@@ -195,6 +195,12 @@ int lsam_mlp_block_pack(const float* fc1_w, const float* fc1_b, const float* fc2
                         void* image, float* bias_table, lsam_stream_t stream);
 int lsam_mlp_block_fwd(const float* x, float* y, const float* norm2_w, const float* norm2_b, const void* image,
                        const float* bias_table, int M, int d, float eps, lsam_stream_t stream);
+/* As lsam_mlp_block_fwd, and also xn_next = LayerNorm(y) with the NEXT block's norm1 parameters (bf16 [M][ldn],
+ * ldn % 4 == 0): `x = self.norm1(x)` of the following MultiScaleBlock (hieradet.py:136), taken from the registers
+ * that hold y, so that block does not read y again for its LayerNorm. */
+int lsam_mlp_block_fwd_next_norm(const float* x, float* y, const float* norm2_w, const float* norm2_b, const void* image,
+                                 const float* bias_table, void* xn_next, int ldn, const float* next_norm_w,
+                                 const float* next_norm_b, int M, int d, float eps, lsam_stream_t stream);
 
 /* Fused tail of a block, bf16 MFMA, in one kernel (stage-2 / stage-3 widths 224 and 448):
  *   y   = res + proj(a)                           (hieradet.py:79,163)

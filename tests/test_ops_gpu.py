@@ -266,6 +266,24 @@ def test_fused_mlp_block(ops, d, M):
     assert torch.equal(y2, y)
 
 
+@pytest.mark.parametrize("d,M", [(112, 4096 + 17), (56, 300), (224, 777)])
+def test_fused_mlp_block_with_next_norm(ops, d, M):
+    """Second output of the fused MLP block: LayerNorm of its result with the next block's norm1 (hieradet.py:136)."""
+    x = rnd(M, d, seed=21)
+    g2, b2 = 1 + 0.1 * rnd(d, seed=22), 0.1 * rnd(d, seed=23)
+    gn, bn = (1 + 0.1 * rnd(d, seed=24)).cuda(), (0.1 * rnd(d, seed=25)).cuda()
+    w1, c1 = rnd(4 * d, d, seed=26) / math.sqrt(d), 0.2 * rnd(4 * d, seed=27)
+    w2, c2 = rnd(d, 4 * d, seed=28) / math.sqrt(4 * d), 0.2 * rnd(d, seed=29)
+    img, bias = ops.mlp_block_pack(w1.cuda(), c1.cuda(), w2.cuda(), c2.cuda())
+    y_plain = ops.mlp_block_fwd(x.cuda(), g2.cuda(), b2.cuda(), img, bias)
+    y, xn = ops.mlp_block_fwd_next_norm(x.cuda(), g2.cuda(), b2.cuda(), img, bias, gn, bn)
+    assert torch.equal(y, y_plain)   # the first output is unchanged, bit for bit
+    want = F.layer_norm(y, (d,), gn, bn, 1e-6)
+    assert rel_err(xn.float().cpu(), want.cpu()) < 1e-2   # bf16 rounding of the output only
+    with pytest.raises(Exception):
+        ops.mlp_block_fwd_next_norm(x.cuda(), g2.cuda(), b2.cuda(), img, bias, gn[1:], bn)   # misaligned gamma
+
+
 def test_fused_mlp_block_rejects_unsupported(ops):
     from image_segmentation_amd._C import LsamError
     with pytest.raises(LsamError):
