@@ -171,7 +171,7 @@ def main():
 
     roofline = None
     if rank == 0:
-        # live per-launch timing of the dominant kernel (gemm2_kernel<bf16, 2, false>: the persistent
+        # live per-launch timing of the dominant kernel (gemm3_kernel<false, false>: the persistent
         # 256x224-tile bf16 MFMA GEMM with bf16 output that runs most block linears): HIP events on
         # the launch stream, recorded inside liblsam (cfg 2224), over `psteps` further steps of the
         # same workload.  achieved = algorithmic 2*M*N*K FLOPs of those launches / their duration.
@@ -200,7 +200,7 @@ def main():
                     "avg_launch_gflop": round(tot_fl / max(1, len(sel)) / 1e9, 3),
                     "algorithmic_hbm_bytes_per_launch": 12 * B * 64 * 64 * 448,
                     "kernel_ms_per_step": round(tot_ms / psteps, 3),
-                    "second_kernel": {"kernel": "lsam::gemm2_kernel<__bf16, 2, false> (256x224 persistent GEMM)",
+                    "second_kernel": {"kernel": "lsam::gemm3_kernel<false, false> (256x224 persistent bf16 GEMM)",
                                       "achieved": round(gemm_tf, 2), "launches_per_step": len(gemm) // psteps,
                                       "kernel_ms_per_step": round(sum(ms[i] for i in gemm) / psteps, 3)},
                     "all_timed_mfma_ms_per_step": round(all_ms / psteps, 3)}

@@ -12,6 +12,8 @@
 // use 128 x 128 with column guards.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "kernels.hpp"
 
 namespace lsam {
@@ -552,6 +554,327 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm2_kernel(const GemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// v3 (bf16, N % 224 == 0): the 256 x 224 tile, DMA scheme and epilogues of v2 with the fragment reads
+// software-pipelined ACROSS the per-k-tile barrier.  In v2 all eight waves leave the barrier together, read their
+// 22 fragments and only then start their 56 MFMAs: the matrix pipes idle for the barrier plus the read latency of
+// every k-tile (measured: the MFMA-only loop ran at 48 % of the MFMA rate).  Here the barrier sits between the two
+// k-steps of a k-tile:
+//     read ks1(q) | MFMA ks0(q) | wait DMA(q+1), barrier | read ks0(q+1), issue DMA(q+2) | MFMA ks1(q)
+// so the first MFMAs behind a barrier have their operands in registers already, and every read has 28 MFMAs to
+// land under.  The reads are inline asm (hipcc drains vmcnt(0) in front of any LDS read it can see behind an
+// LDS-DMA, which would serialise copy and multiply) and are ordered by hand with counted waits.
+// Further differences from v2:
+//  * every wave issues exactly 8 DMA pieces per k-tile (the four spare ones go to the stage's padding rows), so
+//    counted vmcnt waits are exact: behind an epilogue the wait for the next k-tile skips the epilogue's stores
+//    (vmcnt counts in issue order), which then drain under the next tile's first k-tile instead of in front of it;
+//  * the bias slice of an output tile rides with its first k-tile as one of those spare pieces (1 KiB of LDS by
+//    tile parity) and seeds the accumulators as the C operand of the tile's first MFMAs -- no global read sits
+//    between an epilogue's stores and the next tile's first MFMA;
+//  * a last k-tile with K % 64 <= 32 skips its empty second k-step (K = 224, 480).
+// ---------------------------------------------------------------------------------------------
+#ifndef GEMM3
+#define GEMM3 1
+#endif
+typedef __attribute__((address_space(3))) const char* gemm_lds_cp;
+template <int B, int E, typename F> __device__ __forceinline__ void g3_static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        g3_static_for<B + 1, E>(f);
+    }
+}
+template <int OFF, typename V> __device__ __forceinline__ void g3_rd(unsigned addr, V& dst) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+
+template <bool OUTF32, bool POOL>
+__global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
+    using T = bf16;
+    constexpr int MT = 4, NT = 7, BM = 256, BN = 224, NW = 8, BK = 64, A_IT = 4;
+    constexpr int STAGE = 65536;       // 512 rows x 128 B; rows 480..511 only take the padding DMA pieces
+    constexpr int BIAS0 = 2 * STAGE;   // 4 x 1 KiB: fp32 bias slice [224] of a tile, slot = tile count & 3
+
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(gemm_lds_cp)(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+    const int g = lane >> 4, lr = lane & 15;
+    const int M = p.M, N = p.N, K = p.K;
+    const int tiles_n = N / BN, tiles_m = (M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
+    const int G = gridDim.x;
+    const int slot = xcd_remap(blockIdx.x, G);
+    if (slot >= ntiles) return;
+    const T* __restrict__ A = static_cast<const T*>(p.A);
+    const T* __restrict__ Wt = static_cast<const T*>(p.W);
+    const int nkt = (K + BK - 1) / BK;
+    const bool half_last = K - (nkt - 1) * BK <= 32;
+
+    const int lrow = lane >> 3, ck = ((lane & 7) ^ lrow) * 8;
+    const unsigned astep = 64u * (unsigned)p.lda * 2u, wstep = 64u * (unsigned)p.ldw * 2u;
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(A), 0,
+                                                         (int)(((size_t)(M - 1) * p.lda + K) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Wt), 0,
+                                                         (int)(((size_t)(N - 1) * p.ldw + K) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.bias ? p.bias : reinterpret_cast<const float*>(A)), 0, p.bias ? N * 4 : 0, 0x00020000);
+
+    // POOL: see gemm2_kernel
+    const int pTW = POOL ? (p.pool_w < 128 ? p.pool_w : 128) : 1, pTH = POOL ? BM / pTW : 1, pWX = POOL ? pTW / 32 : 1;
+    const int ptx = POOL ? p.pool_w / pTW : 1, pty = POOL ? p.pool_h / pTH : 1;
+    struct DmaAddr { int n0, arow0, wrow0; unsigned aoff0, woff0; unsigned aoffp[POOL ? A_IT : 1]; };
+    auto dma_addr = [&](int t) {
+        DmaAddr a;
+        const int m0 = (t / tiles_n) * BM;
+        a.n0 = (t % tiles_n) * BN;
+        a.arow0 = m0 + 8 * wave + lrow;
+        a.wrow0 = a.n0 + 8 * wave + lrow;
+        a.aoff0 = ((unsigned)a.arow0 * (unsigned)p.lda + ck) * 2u;
+        a.woff0 = ((unsigned)a.wrow0 * (unsigned)p.ldw + ck) * 2u;
+        if constexpr (POOL) {
+            const int tm = t / tiles_n;
+            const int pn = tm / (ptx * pty), py0 = ((tm / ptx) % pty) * pTH, px0 = (tm % ptx) * pTW;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int y = py0 + 2 * (i / pWX) + (wave >> 2), x = px0 + 32 * (i % pWX) + 16 * ((wave >> 1) & 1) + 8 * (wave & 1) + lrow;
+                const unsigned tok = ((unsigned)pn * (unsigned)p.pool_h + (unsigned)y) * (unsigned)p.pool_w + (unsigned)x;
+                a.aoffp[i] = (tok * (unsigned)p.lda + ck) * 2u;
+            }
+        }
+        return a;
+    };
+    // 8 DMA wave-instructions: A rows 8 (wave + 8 i), W rows 8 (wave + 8 i); waves 4..7 have no fourth W piece: theirs
+    // is a zero fill of the stage's padding rows, or (wave 4, first k-tile of an output tile) the tile's bias slice.
+    auto issue = [&](const DmaAddr& ta, int kt, int stage, int bslot) {
+#if LSAM_ABL & 1
+        return;
+#endif
+        const int k0 = kt * BK;
+        const bool kok = k0 + ck < K;
+        const unsigned kb = (unsigned)k0 * 2u;
+        char* base = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            unsigned vo;
+            if constexpr (POOL) vo = kok ? ta.aoffp[i] + kb : 0xFFFFFFFFu;
+            else vo = (ta.arow0 + 64 * i < M && kok) ? ta.aoff0 + i * astep + kb : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_ptr_t)(base + (wave + NW * i) * 1024), 16, vo, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const unsigned vo = kok ? ta.woff0 + i * wstep + kb : 0xFFFFFFFFu;   // N % 224 == 0: every W row exists
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(base + (32 + wave + NW * i) * 1024), 16, vo, 0, 0, 0);
+        }
+        if (wave < 4) {
+            const unsigned vo = kok ? ta.woff0 + 3 * wstep + kb : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(base + (32 + wave + NW * 3) * 1024), 16, vo, 0, 0, 0);
+        } else if (wave == 4 && kt == 0) {
+            const unsigned vo = lane < 56 ? (unsigned)(ta.n0 + 4 * lane) * 4u : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_ptr_t)(smem + BIAS0 + bslot * 1024), 16, vo, 0, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_ptr_t)(base + (32 + wave + NW * 3) * 1024), 16, 0xFFFFFFFFu, 0, 0, 0);
+        }
+    };
+
+    // per-lane fragment read addresses in stage 0 (k-step 1 is chunk ^ 4 of k-step 0)
+    const unsigned chunk0 = (unsigned)((g ^ (lr & 7)) << 4);
+    const unsigned aA0 = lds0 + (unsigned)(wm * 64 + lr) * 128u + chunk0, aA1 = aA0 ^ 64u;
+    const unsigned aW0 = lds0 + (unsigned)(BM + wn * 112 + lr) * 128u + chunk0, aW1 = aW0 ^ 64u;
+
+    // Fragments are held as 4 x u32 and re-typed at the MFMA: as <8 x bf16> values carried round the loop hipcc
+    // re-packs some of them element by element (v_lshrrev / v_perm) at the loop head, i.e. BEFORE the counted wait
+    // that makes the asm read's result valid.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    f32x4 acc[MT][NT];
+    u32x4 af0[MT], wf0[NT], af1[MT], wf1[NT];
+    auto rd_set = [&](unsigned aA, unsigned aW, u32x4 (&af)[MT], u32x4 (&wf)[NT]) {
+        g3_static_for<0, MT>([&](auto i_) { g3_rd<decltype(i_)::value * 2048>(aA, af[decltype(i_)::value]); });
+        g3_static_for<0, NT>([&](auto i_) { g3_rd<decltype(i_)::value * 2048>(aW, wf[decltype(i_)::value]); });
+    };
+    auto mfmas = [&](const u32x4 (&af)[MT], const u32x4 (&wf)[NT]) {
+#if LSAM_ABL & 2
+        return;
+#endif
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                mma16(__builtin_bit_cast(bf16x8, wf[nt]), __builtin_bit_cast(bf16x8, af[mt]), acc[mt][nt]);
+    };
+
+    // ---- epilogues: as in gemm2_kernel, the bias is already in the accumulators ---------------------------
+    const int flags = p.flags;
+    const int lr_c = lr, g_c = g;
+    auto epilogue = [&](int m0, int n0) {
+        int lr = lr_c, g = g_c;
+        asm volatile("" : "+v"(lr), "+v"(g));
+        const int nc = n0 + wn * 112 + 4 * g;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int m = m0 + wm * 64 + mt * 16 + lr;
+            const bool mok = m < M;
+            const int mc = mok ? m : M - 1;
+            auto store_row = [&](auto* base, int ld, const f32x4 (&val)[NT]) {
+                auto* rowp = base + (size_t)mc * ld + n0 + wn * 112;
+                if constexpr (sizeof(*base) == 4) {
+                    if (mok) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) store4(rowp + nt * 16 + 4 * g, val[nt]);
+                    }
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt + 1 < NT; nt += 2) store_bf16_tile_pair(rowp + nt * 16, g, val[nt], val[nt + 1], mok);
+                    if (mok) store4(rowp + (NT - 1) * 16 + 4 * g, val[NT - 1]);
+                }
+            };
+            f32x4 v[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) v[nt] = acc[mt][nt];
+            if (flags & LSAM_EPI_SAVE_PRE) store_row(static_cast<T*>(p.out2), p.ldo2, v);
+            if (flags & LSAM_EPI_GELU) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[nt][r] = gelu_t<true>(v[nt][r]);
+            }
+            if (flags & LSAM_EPI_GELU_BWD) {
+                const T* xp = static_cast<const T*>(p.aux) + (size_t)mc * p.ldaux + nc;
+                f32x4 x[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) x[nt] = load4(xp + 16 * nt);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[nt][r] *= gelu_grad_t<true>(x[nt][r]);
+            }
+            if (p.res) {
+                const float* rp = p.res + (p.res_row_mod > 0 ? (size_t)(mc % p.res_row_mod) : (size_t)mc) * p.ldres + nc;
+                f32x4 rv[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) rv[nt] = load4(rp + 16 * nt);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) v[nt] += rv[nt];
+            }
+            if constexpr (OUTF32) store_row(static_cast<float*>(p.out), p.ldo, v);
+            else store_row(static_cast<bf16*>(p.out), p.ldo, v);
+        }
+    };
+    auto epilogue_pool = [&](int t) {
+        int lr = lr_c, g = g_c;
+        asm volatile("" : "+v"(lr), "+v"(g));
+        const int tm = t / tiles_n, n0 = (t % tiles_n) * BN;
+        const int pn = tm / (ptx * pty), py0 = ((tm / ptx) % pty) * pTH, px0 = (tm % ptx) * pTW;
+        const int nc = n0 + wn * 112 + 4 * g;
+        const int hh = p.pool_h >> 1, hw = p.pool_w >> 1;
+#pragma unroll
+        for (int mp = 0; mp < 2; ++mp) {
+            const int py = (py0 >> 1) + wm / pWX, px = (px0 + 32 * (wm % pWX) + 16 * mp + lr) >> 1;
+            float* rowp = static_cast<float*>(p.out) + (((size_t)pn * hh + py) * hw + px) * p.ldo + nc;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a = fmaxf(acc[mp][nt][r], acc[mp + 2][nt][r]);
+                    const float b = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, true));
+                    v[r] = fmaxf(a, b);
+                }
+                if (!(lr & 1)) store4(rowp + 16 * nt, v);
+            }
+        }
+    };
+
+    // ---- DMA cursor: two k-tiles ahead of the multiply -------------------------------------------------------
+    int dt = slot, dkt = 0, dstage = 0, dit = 0;
+    DmaAddr da = dma_addr(dt);
+    auto dma_next = [&]() {
+        if (dt < ntiles) issue(da, dkt, dstage, dit & 3);
+        dstage ^= 1;
+        if (++dkt == nkt) {
+            dkt = 0;
+            dt += G;
+            ++dit;
+            if (dt < ntiles) da = dma_addr(dt);
+        }
+    };
+    dma_next();
+    const bool second = dt < ntiles;
+    dma_next();
+    if (second) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    rd_set(aA0, aW0, af0, wf0);
+
+    int st = 0, it = 0;
+    int after = 0;   // vector-memory operations this wave issued behind the DMA the next barrier waits for
+    for (int t = slot; t < ntiles; t += G, ++it) {
+#pragma nounroll
+        for (int kt = 0; kt < nkt; ++kt) {
+            const unsigned so = (unsigned)st << 16, sn = so ^ 0x10000u;
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt == 0) {
+                // the bias slice lands in row block 0's accumulators and is the C operand of the tile's first
+                // MFMAs (row block 0 last: it overwrites the bias)
+                // (address rebuilt from the lane id here: kept live across the tile loop it costs a spill whose reload
+                // would put a vmcnt(0) in front of every tile)
+                unsigned ln;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+                const unsigned ab = lds0 + BIAS0 + (unsigned)(wn * 112) * 4u + (ln >> 4) * 16u + (unsigned)(it & 3) * 1024u;
+                g3_static_for<0, NT>([&](auto i_) { g3_rd<decltype(i_)::value * 64>(ab, acc[0][decltype(i_)::value]); });
+                rd_set(aA1 + so, aW1 + so, af1, wf1);
+                asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                    for (int mt = 1; mt < MT; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf0[nt]),
+                                                                              __builtin_bit_cast(bf16x8, af0[mt]), acc[0][nt], 0, 0, 0);
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf0[nt]),
+                                                                         __builtin_bit_cast(bf16x8, af0[0]), acc[0][nt], 0, 0, 0);
+                }
+            } else {
+                rd_set(aA1 + so, aW1 + so, af1, wf1);
+                asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(af0, wf0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the next k-tile has landed (this wave's pieces; the barrier covers the others') and every wave is
+            // done reading this stage
+            if (kt == 0 && after >= 28) asm volatile("s_waitcnt vmcnt(28) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (kt == 0 && after >= 14) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            rd_set(aA0 + sn, aW0 + sn, af0, wf0);
+            __builtin_amdgcn_sched_barrier(0);
+            dma_next();
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(half_last && kt == nkt - 1)) mfmas(af1, wf1);
+            st ^= 1;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the next tile's first fragments are in registers
+        __builtin_amdgcn_sched_barrier(0);
+        const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+#if LSAM_ABL & 4
+        if (acc[0][0][0] == 1.2345e-30f && acc[3][6][3] == 1.2345e-30f) epilogue(m0, n0);
+        after = 0;
+        continue;
+#endif
+        if constexpr (POOL) {
+            epilogue_pool(t);
+            after = 14;
+        } else {
+            epilogue(m0, n0);
+            after = m0 + BM <= M ? (OUTF32 ? 28 : 14) : 0;   // bf16: 16 stores per full tile
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------
 // Optional per-launch timing of the GEMM kernels (bench.py's live roofline measurement).  OFF by
 // default; when armed, every launch is bracketed by a pre-created hipEvent pair on the launch
 // stream.  Process-global and not thread-safe by design: a measurement aid, not part of the path.
@@ -655,6 +978,23 @@ template <typename T, int WN, bool OUTF32, bool POOL = false> static int launch_
     return LSAM_OK;
 }
 
+template <bool OUTF32, bool POOL = false> static int launch_v3(const GemmArgs& a, hipStream_t s) {
+    constexpr int LDS = 2 * 65536 + 4096;
+    auto kern = gemm3_kernel<OUTF32, POOL>;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        LSAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    const int ntiles = cdiv(a.M, 256) * (a.N / 224);
+    const int nblk = ntiles < 256 ? ntiles : 256;   // persistent: one workgroup per CU
+    const int rec = prof_begin(s);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), LDS, s, a);
+    LSAM_LAUNCH_CHECK();
+    prof_end(rec, s, 2.0 * a.M * a.N * a.K, 2000 + 224 + (OUTF32 ? 1 : 0), a.M, a.N, a.K);
+    return LSAM_OK;
+}
+
 // pooled epilogue: whole TH x TW patches (TW = min(W, 128) a multiple of 32, TH = 256 / TW), 224-wide column tiles
 bool gemm_pool_supported(int H, int W, int N) {
     if (H <= 0 || W <= 0 || W % 32 != 0 || N % 224 != 0) return false;
@@ -685,6 +1025,7 @@ template <typename T> int launch_gemm(const GemmArgs& a, hipStream_t s) {
                              (a.flags & ~LSAM_EPI_OUT_F32) == 0 && (a.flags & LSAM_EPI_OUT_F32) && !a.res &&
                              (double)a.M * a.lda * sizeof(T) < 2.0e9 && (double)a.N * a.ldw * sizeof(T) < 2.0e9,
                          LSAM_ERR_UNSUPPORTED, "linear: pooled epilogue not available for this shape");
+            if (GEMM3) return launch_v3<true, true>(a, s);
             return launch_v2<T, 2, true, true>(a, s);
         } else {
             set_error("linear: pooled epilogue is bf16 only");
@@ -698,6 +1039,9 @@ template <typename T> int launch_gemm(const GemmArgs& a, hipStream_t s) {
 #ifndef GEMM2_FORCE_WN1
 #define GEMM2_FORCE_WN1 0
 #endif
+        if constexpr (sizeof(T) == 2) {
+            if (GEMM3 && a.N % 224 == 0 && !GEMM2_FORCE_WN1) return of32 ? launch_v3<true>(a, s) : launch_v3<false>(a, s);
+        }
         if (a.N % 224 == 0 && !GEMM2_FORCE_WN1) return of32 ? launch_v2<T, 2, true>(a, s) : launch_v2<T, 2, sizeof(T) == 4>(a, s);
         return of32 ? launch_v2<T, 1, true>(a, s) : launch_v2<T, 1, sizeof(T) == 4>(a, s);
     }

@@ -46,6 +46,26 @@ def test_linear_bias_res(ops, dt, M, N, K):
     assert rel_err(out_t.float(), ref - res.double()) < tol(dt, 1e-6, 5e-3)
 
 
+@pytest.mark.parametrize("M,N,K", [(33000, 672, 224), (20000, 1344, 480), (70000, 224, 64), (66000, 448, 32),
+                                   (40000, 448, 448), (140000, 224, 896)])
+def test_linear_persistent_many_tiles(ops, M, N, K):
+    """bf16, N % 224 == 0, more output tiles than workgroups: every workgroup of the persistent kernel walks several
+    tiles (pipelined k-tiles across tile boundaries, bias slices by tile parity, ragged last row tile, K tails that
+    end in the first k-step of a k-tile, single-k-tile products)."""
+    dt = torch.bfloat16
+    A, W = rnd(M, K, seed=1).cuda().to(dt), (rnd(N, K, seed=2) / math.sqrt(K)).cuda().to(dt)
+    b, res = rnd(N, seed=3).cuda(), rnd(M, N, seed=4).cuda()
+    ref = A.double() @ W.double().t() + b.double()
+    out = ops.linear(A, W, b, res=res, out_f32=True)
+    assert rel_err(out.double(), ref + res.double()) < 1e-6
+    out = ops.linear(A, W, b)
+    assert rel_err(out.double(), ref) < 5e-3
+    out = ops.linear(A, W, None, out_f32=True)
+    assert rel_err(out.double(), ref - b.double()) < 1e-6
+    out, pre = ops.linear(A, W, b, gelu=True, save_pre=True)
+    assert rel_err(pre.double(), ref) < 5e-3 and rel_err(out.double(), F.gelu(ref)) < 5e-3
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M", [192, 1216])
 def test_linear_epilogues(ops, dt, M):
