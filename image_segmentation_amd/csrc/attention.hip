@@ -375,8 +375,11 @@ __device__ uint4 g_attn_one16 = {0x00003F80u, 0u, 0u, 0u};   // bf16 1.0 followe
 // ONES (head_dim <= 56): the first padding channel of every valid key's V row is fed as 1.0 (its 16-byte chunk
 // is DMA'd from g_attn_one16 instead of the zero word), so channel hd of the output accumulates the softmax
 // denominator in the PV MFMAs: no per-element adds on the VALU, which is what bounds this kernel.
+#ifndef ATTN2_QT
+#define ATTN2_QT 4
+#endif
 template <int QT, bool ONES>
-__global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnArgs p, const float c_log2) {
+__global__ __launch_bounds__(256, QT == 2 ? 3 : 2) void attn2_fwd_kernel(const AttnArgs p, const float c_log2) {
     using T = bf16;
     constexpr int KT2 = 64, RB = 128, TILE_B = KT2 * RB, STAGE = 2 * TILE_B, DT = 4;
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
@@ -434,6 +437,8 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnArgs p, con
                         }
                 }
             }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= c_log2;   // scores come out of the MFMAs in log2 units
             qf[qt][ks] = frag_from_f<T>(v);
         }
     }
@@ -473,11 +478,15 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnArgs p, con
         }
     };
 
-    f32x4 o[QT][DT];
-    float mrun[QT], lrun[QT];
+    // Running row maximum, kept NEGATED and replicated as the C operand of the score MFMAs: the scores come out of
+    // the matrix pipe as s - m (log2 units, the scale is folded into Q), so the common case -- no row's maximum
+    // moved -- is one v_exp_f32 per score with no subtract in front of it.  The first tile runs against m = 0 and
+    // always takes the re-centring path.
+    f32x4 o[QT][DT], negm[QT];
+    float lrun[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        mrun[qt] = -1.0e30f;
+        negm[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
         lrun[qt] = 0.f;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -508,12 +517,12 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnArgs p, con
         for (int qt = 0; qt < QT; ++qt) {
             f32x4 s[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {   // C = 0 goes in as the MFMA's inline constant: no zero-fill moves
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][0], qf[qt][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            for (int t = 0; t < 4; ++t) {
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][0], qf[qt][0], negm[qt], 0, 0, 0);
                 s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][1], qf[qt][1], s[t], 0, 0, 0);
             }
-            // online softmax on the RAW scores (scale folded into the exponent's fma); the O / l
-            // rescale only runs when some row's maximum actually moved (exact, not a threshold)
+            // online softmax on s - m; O (and l) are rescaled only when some row's maximum actually moved
+            // (exact, not a threshold)
             if (tail) {   // block-uniform: only the last tile of a window pays for the key mask
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
@@ -525,15 +534,21 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnArgs p, con
 #pragma unroll
             for (int t = 1; t < 4; ++t) mx = fmaxf(fmaxf(mx, s[t][0]), fmaxf(fmaxf(s[t][1], s[t][2]), s[t][3]));
             mx = group4_max(mx);
-            const float mnew = fmaxf(mrun[qt], mx);
-            if (__any(mnew != mrun[qt])) {
-                const float alpha = __builtin_amdgcn_exp2f((mrun[qt] - mnew) * c_log2);
-                mrun[qt] = mnew;
-                if constexpr (!ONES) lrun[qt] *= alpha;
+            if (tile == 0 || __any(mx > 0.f)) {
+                const float d = tile == 0 ? mx : fmaxf(mx, 0.f);   // how far this row's maximum moved
+                if (tile != 0) {
+                    const float alpha = __builtin_amdgcn_exp2f(-d);
+                    if constexpr (!ONES) lrun[qt] *= alpha;
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+                    for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) negm[qt][r] -= d;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[t][r] -= d;
             }
-            const float mneg = -mnew * c_log2;
             float psum = 0.f;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -542,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnArgs p, con
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float e = __builtin_amdgcn_exp2f(fmaf(s[2 * u + t][r], c_log2, mneg));
+                        const float e = __builtin_amdgcn_exp2f(s[2 * u + t][r]);
                         pv[t * 4 + r] = e;
                         if constexpr (!ONES) psum += e;
                     }
@@ -607,7 +622,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const AttnArgs p, con
             if (d0 < hd) store4(out + (size_t)qtok[qt] * p.ldo + h * hd + d0, o[qt][dt] * inv);
         }
         if (p.lse && g == 0)
-            p.lse[(size_t)qtok[qt] * nh + h] = (mrun[qt] * c_log2 + log2f(l)) * 0.69314718055994531f;
+            p.lse[(size_t)qtok[qt] * nh + h] = (log2f(l) - negm[qt][0]) * 0.69314718055994531f;
     }
 }
 
@@ -859,7 +874,7 @@ template <typename T> int launch_attn_fwd(const AttnArgs& a, hipStream_t s) {
         if (a.bias_t && a.hd <= 64 && a.ws > 0 && G.wsh * G.wsw > 64 && G.wsh * G.wsw <= 208 && max_nq > 64 && a.ldqkv % 8 == 0)
             return attnw_launch(a, s);   // (pooled windows have few queries per staged K/V tile: the streaming kernel below)
         if (a.bias_t && a.hd <= 64 && G.wsh * G.wsw >= 128 && max_nq >= 32 && a.ldqkv % 8 == 0) {
-            if (max_nq > 64) return attn2_launch<4>(a, cdiv(max_nq, 256), s);
+            if (max_nq > 64) return attn2_launch<ATTN2_QT>(a, cdiv(max_nq, 64 * ATTN2_QT), s);
             return attn2_launch<1>(a, 1, s);
         }
     }
