@@ -65,18 +65,20 @@ __global__ __launch_bounds__(256, 2) void patch_embed_kernel(const float* __rest
         qoff[ks] = (c * PE_R + ky) * PE_PITCH;
     }
 
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // A thread's input words of a tile are all requested together (one memory round trip per tile, not one per loop
+    // iteration) and before the barrier that frees the LDS tile: they overlap the tail of the other waves' compute on
+    // the previous tile.  (Requesting them a whole tile ahead needs 56 more live registers than the kernel has:
+    // 199 spilled registers, measured.)
+    constexpr int NLD = (3 * PE_R * PE_C4 + 255) / 256;
+    f32x4 ld[NLD];
+    auto request = [&](int t) {
         const int n = t / (tiles_x * tiles_y), tr = t % (tiles_x * tiles_y);
-        const int oy0 = (tr / tiles_x) * PE_TY, ox0 = (tr % tiles_x) * PE_TX;
-        const int iy0 = 4 * oy0 - 3, ix0 = 4 * ox0 - 3;
-        // all of this thread's input words are requested before any is used (one memory round trip per tile, not one
-        // per loop iteration), and before the barrier that frees the LDS tile: they overlap the tail of the other waves'
-        // compute on the previous tile
-        constexpr int NLD = (3 * PE_R * PE_C4 + 255) / 256;
-        f32x4 ld[NLD];
+        const int iy0 = 4 * (tr / tiles_x) * PE_TY - 3, ix0 = 4 * (tr % tiles_x) * PE_TX - 3;
+        int tid_ = tid;   // opaque per call: keeps the 14 words' lane-constant address arithmetic out of the tile loop's
+        asm volatile("" : "+v"(tid_));   // live registers (hoisted, it spills the accumulators)
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
-            const int i = tid + 256 * it;
+            const int i = tid_ + 256 * it;
             const int c4 = i % PE_C4, rr = i / PE_C4, r = rr % PE_R, c = rr / PE_R;
             const int iy = iy0 + r, ix = ix0 + 4 * c4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -93,6 +95,25 @@ __global__ __launch_bounds__(256, 2) void patch_embed_kernel(const float* __rest
             }
             ld[it] = v;
         }
+    };
+
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int n = t / (tiles_x * tiles_y), tr = t % (tiles_x * tiles_y);
+        const int oy0 = (tr / tiles_x) * PE_TY, ox0 = (tr % tiles_x) * PE_TX;
+        request(t);
+        // the accumulators start at the position embedding: requested here, behind the input words (vmcnt retires in
+        // order, so staging does not wait for them), they land under the two barriers and the staging stores
+        f32x4 acc[4][NT];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int oy = min(oy0 + 2 * wave + (mt >> 1), G - 1), ox = min(ox0 + 16 * (mt & 1) + lr, G - 1);
+            const float* pp = pos + ((size_t)oy * G + ox) * e0;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int c0 = 16 * nt + 4 * g;
+                acc[mt][nt] = c0 < e0 ? load4(pp + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
         __syncthreads();   // every wave is done with the previous tile (and the weight copy is visible)
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
@@ -105,14 +126,12 @@ __global__ __launch_bounds__(256, 2) void patch_embed_kernel(const float* __rest
             }
         }
         __syncthreads();
-
-        f32x4 acc[4][NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int c0 = 16 * nt + 4 * g;
             const f32x4 b = c0 < e0 ? load4(bias + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = b;
+            for (int mt = 0; mt < 4; ++mt) acc[mt][nt] += b;
         }
 #pragma unroll
         for (int ks = 0; ks < PE_KS; ++ks) {
@@ -136,13 +155,11 @@ __global__ __launch_bounds__(256, 2) void patch_embed_kernel(const float* __rest
         for (int mt = 0; mt < 4; ++mt) {
             const int oy = oy0 + 2 * wave + (mt >> 1), ox = ox0 + 16 * (mt & 1) + lr;
             if (oy < G && ox < G) {
-                const size_t pix = (size_t)oy * G + ox;
-                const float* pp = pos + pix * e0;
-                float* op = out + ((size_t)n * G * G + pix) * e0;
+                float* op = out + ((size_t)n * G * G + (size_t)oy * G + ox) * e0;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int c0 = 16 * nt + 4 * g;
-                    if (c0 < e0) store4(op + c0, acc[mt][nt] + load4(pp + c0));
+                    if (c0 < e0) store4(op + c0, acc[mt][nt]);
                 }
             }
         }
