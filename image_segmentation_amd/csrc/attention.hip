@@ -637,12 +637,20 @@ __global__ __launch_bounds__(256, QT == 2 ? 3 : 2) void attn2_fwd_kernel(const A
 // overlap one's staging with the other's MFMAs.
 // ---------------------------------------------------------------------------------------------
 template <int NKT>
-__global__ __launch_bounds__(256) void attnw_fwd_kernel(const AttnArgs p, const float c_log2) {
+#ifndef ATTNW_WPS
+#define ATTNW_WPS 3
+#endif
+__global__ __launch_bounds__(256, ATTNW_WPS) void attnw_fwd_kernel(const AttnArgs p, const float c_log2) {
     using T = bf16;
-    constexpr int U = (NKT + 1) / 2, NKP = 32 * U, RB = 128, TILE_B = NKP * RB, DT = 4;
+    // 16 NKT rows per operand, V first: the PV MFMAs take keys 32 at a time, and for an odd NKT the upper half of
+    // the last pair (rows 16 NKT .. 16 NKT + 15 of V) is then the first 16 rows of K -- finite values against
+    // probabilities that are exactly zero -- instead of 4 KiB of padding.  52 KiB instead of 56 per workgroup is
+    // what lets THREE workgroups share a CU's 160 KiB (with waves of <= 168 registers): the kernel is bound by
+    // the latency of its one-shot K/V staging, so residency is what it needs.
+    constexpr int U = (NKT + 1) / 2, NKR = 16 * NKT, RB = 128, TILE_B = NKR * RB, DT = 4;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    char* kb = smem;
-    char* vb = smem + TILE_B;
+    char* vb = smem;
+    char* kb = smem + TILE_B;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -664,14 +672,14 @@ __global__ __launch_bounds__(256) void attnw_fwd_kernel(const AttnArgs p, const 
     const size_t img_tok = (size_t)n * H * W;
 
     const bool ones = hd % 8 == 0 && hd <= 56;   // kernel-uniform
-    // ---- stage K and V: DMA instruction j covers tile rows 8j .. 8j+7 of K (j < NKP/8) or V --------
+    // ---- stage K and V: DMA instruction j covers tile rows 8j .. 8j+7 of V (j < 2 NKT) or K -------
     {
         const int lrow = lane >> 3, dsrc = ((lane & 7) ^ lrow) * 8;   // swizzle applied on the source side
         const bool dok = dsrc < hd;
-        constexpr int NI = NKP / 8;
+        constexpr int NI = NKR / 8;
 #pragma unroll 1
         for (int j = wave; j < 2 * NI; j += 4) {
-            const int v = j >= NI ? 1 : 0, kk = 8 * (j - v * NI) + lrow;
+            const int v = j < NI ? 1 : 0, kk = 8 * (j - (1 - v) * NI) + lrow;
             const int ky = kk / G.wsw, kx = kk - ky * G.wsw;
             const int y = wy * G.wsh + ky, x = wx * G.wsw + kx;
             const void* src = &g_attn_zero16;
@@ -813,7 +821,7 @@ __global__ __launch_bounds__(256) void attnw_fwd_kernel(const AttnArgs p, const 
 }
 
 static int attnw_launch(const AttnArgs& a, hipStream_t s) {
-    constexpr int NKT = 13, LDSB = 2 * 32 * ((NKT + 1) / 2) * 128;
+    constexpr int NKT = 13, LDSB = 2 * 16 * NKT * 128;
     const WinGeom G = make_geom(a.H, a.W, a.ws, a.pool);
     const float c = (1.0f / sqrtf((float)a.hd)) * 1.4426950408889634f;
     static thread_local bool attr_set = false;
