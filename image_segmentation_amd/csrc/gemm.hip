@@ -843,8 +843,8 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
             __builtin_amdgcn_sched_barrier(0);
             // the next k-tile has landed (this wave's pieces; the barrier covers the others') and every wave is
             // done reading this stage
-            if (kt == 0 && after >= 28) asm volatile("s_waitcnt vmcnt(28) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else if (kt == 0 && after >= 14) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kt == 0 && after >= 24) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (kt == 0 && after >= 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             rd_set(aA0 + sn, aW0 + sn, af0, wf0);
@@ -865,10 +865,10 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
 #endif
         if constexpr (POOL) {
             epilogue_pool(t);
-            after = 14;
+            after = 12;   // 14 stores; counted a little short so that a store the compiler fuses or drops cannot matter
         } else {
             epilogue(m0, n0);
-            after = m0 + BM <= M ? (OUTF32 ? 28 : 14) : 0;   // bf16: 16 stores per full tile
+            after = m0 + BM <= M ? (OUTF32 ? 24 : 12) : 0;   // full tile: 28 (fp32) / 16 (bf16) stores, counted short
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
