@@ -575,6 +575,12 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm2_kernel(const GemmArgs p) {
 #ifndef GEMM3
 #define GEMM3 1
 #endif
+// Where a k-tile's 8 DMA pieces are issued: 0 = right behind the barrier, in front of the second MFMA block;
+// 1 = behind it.  Stand-alone, 1 is 5-11 % faster on some shapes (16384 x 896 x 3584) and 6 % slower on others;
+// over the whole training step it loses (837 vs 851 frames/s), so 0 it is.
+#ifndef GEMM3_DMA_POS
+#define GEMM3_DMA_POS 0
+#endif
 typedef __attribute__((address_space(3))) const char* gemm_lds_cp;
 template <int B, int E, typename F> __device__ __forceinline__ void g3_static_for(F&& f) {
     if constexpr (B < E) {
@@ -849,9 +855,15 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
             __builtin_amdgcn_sched_barrier(0);
             rd_set(aA0 + sn, aW0 + sn, af0, wf0);
             __builtin_amdgcn_sched_barrier(0);
+#if GEMM3_DMA_POS == 0
             dma_next();
             __builtin_amdgcn_sched_barrier(0);
+#endif
             if (!(half_last && kt == nkt - 1)) mfmas(af1, wf1);
+#if GEMM3_DMA_POS == 1
+            __builtin_amdgcn_sched_barrier(0);
+            dma_next();
+#endif
             st ^= 1;
         }
         __builtin_amdgcn_sched_barrier(0);
