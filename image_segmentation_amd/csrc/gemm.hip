@@ -575,11 +575,12 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm2_kernel(const GemmArgs p) {
 #ifndef GEMM3
 #define GEMM3 1
 #endif
-// Where a k-tile's 8 DMA pieces are issued: 0 = right behind the barrier, in front of the second MFMA block;
-// 1 = behind it.  Stand-alone, 1 is 5-11 % faster on some shapes (16384 x 896 x 3584) and 6 % slower on others;
-// over the whole training step it loses (837 vs 851 frames/s), so 0 it is.
+// Where a k-tile's 8 DMA pieces are issued: 0 = in one burst right behind the barrier, in front of the second MFMA
+// block; 1 = in one burst behind that block; 2 = one piece in front of every 3-4 MFMAs of that block.  Stand-alone,
+// 1 is 5-11 % faster than 0 on some shapes (16384 x 896 x 3584) and 6 % slower on others, and over the whole
+// training step it loses (837 vs 851 frames/s); 2 is the best of the three there (852.6 vs 850.2, A/B/A/B on one box).
 #ifndef GEMM3_DMA_POS
-#define GEMM3_DMA_POS 0
+#define GEMM3_DMA_POS 2
 #endif
 typedef __attribute__((address_space(3))) const char* gemm_lds_cp;
 template <int B, int E, typename F> __device__ __forceinline__ void g3_static_for(F&& f) {
@@ -679,6 +680,35 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_ptr_t)(smem + BIAS0 + bslot * 1024), 16, vo, 0, 0, 0);
         } else {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_ptr_t)(base + (32 + wave + NW * 3) * 1024), 16, 0xFFFFFFFFu, 0, 0, 0);
+        }
+    };
+
+    // one of the 8 pieces (compile-time index), for the interleaved placement (GEMM3_DMA_POS == 2)
+    auto issue_piece = [&](const DmaAddr& ta, int kt, int stage, int bslot, auto idx_) {
+        constexpr int idx = decltype(idx_)::value;
+        const int k0 = kt * BK;
+        const bool kok = k0 + ck < K;
+        const unsigned kb = (unsigned)k0 * 2u;
+        char* base = smem + stage * STAGE;
+        if constexpr (idx < A_IT) {
+            unsigned vo;
+            if constexpr (POOL) vo = kok ? ta.aoffp[idx] + kb : 0xFFFFFFFFu;
+            else vo = (ta.arow0 + 64 * idx < M && kok) ? ta.aoff0 + idx * astep + kb : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_ptr_t)(base + (wave + NW * idx) * 1024), 16, vo, 0, 0, 0);
+        } else if constexpr (idx < A_IT + 3) {
+            constexpr int i = idx - A_IT;
+            const unsigned vo = kok ? ta.woff0 + i * wstep + kb : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(base + (32 + wave + NW * i) * 1024), 16, vo, 0, 0, 0);
+        } else {
+            if (wave < 4) {
+                const unsigned vo = kok ? ta.woff0 + 3 * wstep + kb : 0xFFFFFFFFu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(base + (32 + wave + NW * 3) * 1024), 16, vo, 0, 0, 0);
+            } else if (wave == 4 && kt == 0) {
+                const unsigned vo = lane < 56 ? (unsigned)(ta.n0 + 4 * lane) * 4u : 0xFFFFFFFFu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_ptr_t)(smem + BIAS0 + bslot * 1024), 16, vo, 0, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_ptr_t)(base + (32 + wave + NW * 3) * 1024), 16, 0xFFFFFFFFu, 0, 0, 0);
+            }
         }
     };
 
@@ -794,6 +824,15 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
     // ---- DMA cursor: two k-tiles ahead of the multiply -------------------------------------------------------
     int dt = slot, dkt = 0, dstage = 0, dit = 0;
     DmaAddr da = dma_addr(dt);
+    auto dma_advance = [&]() {
+        dstage ^= 1;
+        if (++dkt == nkt) {
+            dkt = 0;
+            dt += G;
+            ++dit;
+            if (dt < ntiles) da = dma_addr(dt);
+        }
+    };
     auto dma_next = [&]() {
         if (dt < ntiles) issue(da, dkt, dstage, dit & 3);
         dstage ^= 1;
@@ -859,7 +898,26 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
             dma_next();
             __builtin_amdgcn_sched_barrier(0);
 #endif
+#if GEMM3_DMA_POS == 2
+            {
+                const bool live = dt < ntiles, mm = !(half_last && kt == nkt - 1);
+                g3_static_for<0, 8>([&](auto c_) {
+                    constexpr int c = decltype(c_)::value;
+                    if (live) issue_piece(da, dkt, dstage, dit & 3, c_);
+                    if (mm) {
+#pragma unroll
+                        for (int e = (28 * c) / 8; e < (28 * (c + 1)) / 8; ++e) {
+                            const int nt = e / MT, mt = e % MT;
+                            mma16(__builtin_bit_cast(bf16x8, wf1[nt]), __builtin_bit_cast(bf16x8, af1[mt]), acc[mt][nt]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                dma_advance();
+            }
+#else
             if (!(half_last && kt == nkt - 1)) mfmas(af1, wf1);
+#endif
 #if GEMM3_DMA_POS == 1
             __builtin_amdgcn_sched_barrier(0);
             dma_next();
