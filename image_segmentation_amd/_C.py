@@ -82,6 +82,7 @@ def lib() -> C.CDLL:
         L.lsam_layernorm_fwd.argtypes = [i, vp, i, vp, vp, vp, i, vp, i, i, f, vp]
         L.lsam_layernorm_bwd.argtypes = [i, vp, i, vp, i, vp, vp, vp, i, vp, i, vp, i, i, i, vp]
         L.lsam_attention_fwd.argtypes = [i, vp, i, vp, vp, vp, i, vp, i, i, i, i, i, i, i, vp]
+        L.lsam_attention_fwd_pooled_q.argtypes = [i, vp, i, vp, vp, vp, i, vp, i, vp, i, i, i, i, i, i, vp]
         L.lsam_attention_bwd.argtypes = [i, vp, i, vp, vp, i, vp, vp, i, i, i, i, i, i, i, vp]
         L.lsam_maxpool2x2.argtypes = [vp, vp, i, i, i, i, vp]
         L.lsam_spatial_mean.argtypes = [vp, vp, i, i, i, vp]
@@ -142,5 +143,5 @@ EXPORTED = [
     "lsam_window_block_fwd", "lsam_mlp_block_image_bytes", "lsam_mlp_block_bias_floats", "lsam_mlp_block_pack",
     "lsam_mlp_block_fwd", "lsam_tail_block_image_bytes", "lsam_tail_block_vec_floats", "lsam_tail_block_pack",
     "lsam_tail_block_fwd", "lsam_patch_embed_image_bytes", "lsam_patch_embed_pack", "lsam_patch_embed_fwd", "lsam_linear_maxpool2x2",
-    "lsam_lateral_conv_image_bytes", "lsam_lateral_conv_pack", "lsam_lateral_conv_fwd", "lsam_mlp_block_fwd_next_norm",
+    "lsam_lateral_conv_image_bytes", "lsam_lateral_conv_pack", "lsam_lateral_conv_fwd", "lsam_mlp_block_fwd_next_norm", "lsam_attention_fwd_pooled_q",
 ]

@@ -144,7 +144,12 @@ __global__ void attn_fwd_kernel(const AttnArgs p, const float c_log2) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = 0.f;
             if (qv && d0 < hd) {
-                if (p.pool == 1) {
+                if (p.qpool) {   // pooled in the qkv GEMM's epilogue: max is monotonic under the bf16 rounding, same bits
+                    const float* qs = p.qpool + (size_t)qtok[qt] * p.ldqp + h * hd + d0;
+                    const f32x4 q0 = load4(qs), q1 = load4(qs + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] = q0[j]; v[4 + j] = q1[j]; }
+                } else if (p.pool == 1) {
                     const size_t tok = img_tok + (size_t)(wy * G.wsh + iy) * W + (wx * G.wsw + ix);
                     load8f<T>(qkv + tok * p.ldqkv + h * hd + d0, v);
                 } else if (p.pool == 2) {
@@ -417,7 +422,12 @@ __global__ __launch_bounds__(256, QT == 2 ? 3 : 2) void attn2_fwd_kernel(const A
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = 0.f;
             if (qv && d0 < hd) {
-                if (p.pool == 1) {
+                if (p.qpool) {   // pooled in the qkv GEMM's epilogue: max is monotonic under the bf16 rounding, same bits
+                    const float* qs = p.qpool + (size_t)qtok[qt] * p.ldqp + h * hd + d0;
+                    const f32x4 q0 = load4(qs), q1 = load4(qs + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] = q0[j]; v[4 + j] = q1[j]; }
+                } else if (p.pool == 1) {
                     const size_t tok = img_tok + (size_t)(wy * G.wsh + iy) * W + (wx * G.wsw + ix);
                     load8f<T>(qkv + tok * p.ldqkv + h * hd + d0, v);
                 } else if (p.pool == 2) {
@@ -710,7 +720,12 @@ __global__ __launch_bounds__(256, ATTNW_WPS) void attnw_fwd_kernel(const AttnArg
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = 0.f;
             if (qv && d0 < hd) {
-                if (p.pool == 1) {
+                if (p.qpool) {   // pooled in the qkv GEMM's epilogue: max is monotonic under the bf16 rounding, same bits
+                    const float* qs = p.qpool + (size_t)qtok_all[i] * p.ldqp + h * hd + d0;
+                    const f32x4 q0 = load4(qs), q1 = load4(qs + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] = q0[j]; v[4 + j] = q1[j]; }
+                } else if (p.pool == 1) {
                     const size_t tok = img_tok + (size_t)(wy * G.wsh + iy) * W + (wx * G.wsw + ix);
                     load8f<T>(qkv + tok * p.ldqkv + h * hd + d0, v);
                 } else if (p.pool == 2) {
@@ -870,6 +885,8 @@ template <typename T> int launch_attn_fwd(const AttnArgs& a, hipStream_t s) {
     LSAM_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.nh > 0 && a.hd > 0, LSAM_ERR_BAD_ARG, "attention: empty shape");
     LSAM_REQUIRE(a.hd % 8 == 0 && a.hd <= 128, LSAM_ERR_UNSUPPORTED, "attention: head_dim %d (need %%8==0, <=128)", a.hd);
     LSAM_REQUIRE(a.pool == 1 || a.pool == 2, LSAM_ERR_UNSUPPORTED, "attention: q-pool stride %d", a.pool);
+    LSAM_REQUIRE(!a.qpool || (a.pool == 2 && a.ldqp >= a.nh * a.hd && a.ldqp % 4 == 0 && aligned16(a.qpool)),
+                 LSAM_ERR_BAD_ARG, "attention: pooled q needs pool == 2, ld %% 4 == 0 and 16-byte alignment");
     LSAM_REQUIRE(a.ws >= 0 && (a.pool == 1 || (a.ws > 0 && a.ws % 2 == 0 && a.H % 2 == 0 && a.W % 2 == 0)),
                  LSAM_ERR_UNSUPPORTED, "attention: pooled blocks need an even window and grid (ws=%d)", a.ws);
     LSAM_REQUIRE(a.ldqkv >= 3 * a.nh * a.hd && a.ldqkv % EPC == 0 && a.ldo >= a.nh * a.hd && a.ldo % 4 == 0 &&

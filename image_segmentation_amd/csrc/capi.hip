@@ -79,6 +79,17 @@ int lsam_attention_fwd(int dtype, const void* qkv, int ldqkv, const float* bias,
     DISPATCH(dtype, launch_attn_fwd<float>(a, s), launch_attn_fwd<bf16>(a, s));
 }
 
+int lsam_attention_fwd_pooled_q(int dtype, const void* qkv, int ldqkv, const float* bias, const void* bias_t,
+                                const float* q_pooled, int ld_qp, void* out, int ldo, float* lse, int N, int H, int W,
+                                int ws, int nh, int hd, lsam_stream_t stream) {
+    LSAM_REQUIRE(q_pooled, LSAM_ERR_BAD_ARG, "attention_fwd_pooled_q: q_pooled is null");
+    AttnArgs a{qkv, ldqkv, bias, out, ldo, lse, N, H, W, ws, 2, nh, hd, bias_t};
+    a.qpool = q_pooled;
+    a.ldqp = ld_qp;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DISPATCH(dtype, launch_attn_fwd<float>(a, s), launch_attn_fwd<bf16>(a, s));
+}
+
 int lsam_attention_bwd(int dtype, const void* qkv, int ldqkv, const float* bias, const void* dout, int lddo,
                        const float* lse, void* dqkv, int lddqkv, int N, int H, int W, int ws, int nh, int hd,
                        lsam_stream_t stream) {

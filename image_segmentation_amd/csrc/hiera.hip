@@ -321,12 +321,31 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
         }
         // ---- qkv (+LoRA through the augmented K columns) ------------------------------------------
         T* qkv = grad ? at<T>(ws, w.sv[gi].qkv) : at<T>(ws, w.qkv);
-        LSAM_TRY(linear<T>(xn, g.kq, at<T>(arena, o.wqkv), g.kq, at<float>(arena, o.bqkv), nullptr, 0, 0, nullptr, 0,
-                           qkv, 3 * q, nullptr, 0, 0, Mi, 3 * q, g.kq, s));
+        // q-pool blocks: the q third of the projection goes through the GEMM's pooling epilogue (only the pooled
+        // queries, a quarter of the rows, ever exist: do_pool(q), hieradet.py:69-71) and only k | v are written at
+        // full resolution.  The pooled shortcut above leaves its un-pooled scratch free for them.
+        const bool qpooled = g.pool == 2 && d != q && sizeof(T) == 2 && !g.lora && !grad && (q / g.heads) % 8 == 0 &&
+                             gemm_pool_supported(g.gin, g.gin, q) && (2 * q) % 224 == 0 && Mi >= 1024;
+        float* qp = nullptr;
+        if (qpooled) {
+            qp = at<float>(ws, w.scpre);
+            GemmArgs gq{xn, g.kq, at<T>(arena, o.wqkv), g.kq, at<float>(arena, o.bqkv), nullptr, 0, 0, nullptr, 0, qp, q,
+                        nullptr, 0, LSAM_EPI_OUT_F32, Mi, q, g.kq};
+            gq.pool_h = g.gin;
+            gq.pool_w = g.gin;
+            LSAM_TRY(launch_gemm<T>(gq, s));
+            LSAM_TRY(linear<T>(xn, g.kq, at<T>(arena, o.wqkv) + (size_t)q * g.kq, g.kq, at<float>(arena, o.bqkv) + q, nullptr, 0,
+                               0, nullptr, 0, qkv + q, 3 * q, nullptr, 0, 0, Mi, 2 * q, g.kq, s));
+        } else {
+            LSAM_TRY(linear<T>(xn, g.kq, at<T>(arena, o.wqkv), g.kq, at<float>(arena, o.bqkv), nullptr, 0, 0, nullptr, 0,
+                               qkv, 3 * q, nullptr, 0, 0, Mi, 3 * q, g.kq, s));
+        }
         // ---- attention ------------------------------------------------------------------------------
         T* a = at<T>(ws, w.a);
         AttnArgs aa{qkv, 3 * q, at<float>(arena, o.bqkv), a, q, grad ? at<float>(ws, w.sv[gi].lse) : nullptr,
                     N, g.gin, g.gin, g.ws, g.pool, g.heads, q / g.heads, at<T>(arena, o.bqkvT)};
+        aa.qpool = qp;
+        aa.ldqp = q;
         LSAM_TRY(launch_attn_fwd<T>(aa, s));
         if (g.fused_tail) {   // proj + residual + norm2 + MLP + residual (+ the next block's norm1), one kernel
             const bool next_ln = !last && !h->blk[i + 1].fused_attn && !h->blk[i + 1].lora && h->blk[i + 1].dim == q;

@@ -43,6 +43,9 @@ struct AttnArgs {
     float* lse;
     int N, H, W, ws, pool, nh, hd;
     const void* bias_t;  // optional T-typed copy of bias (enables the LDS-DMA kernel)
+    // optional (pool == 2): q already max-pooled, fp32 [N*(H/2)*(W/2)][ldqp] in output-token order (the q columns
+    // of the qkv GEMM taken through the pooling epilogue); the q columns of qkv are then never read
+    const float* qpool = nullptr; int ldqp = 0;
 };
 template <typename T> int launch_attn_fwd(const AttnArgs& a, hipStream_t s);
 

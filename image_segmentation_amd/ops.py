@@ -105,8 +105,9 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, gamma:
 
 
 def attention_fwd(qkv: torch.Tensor, bias: torch.Tensor, ws: int, pool: int, nh: int,
-                  want_lse: bool = False):
-    """qkv T [N,H,W,3*nh*hd] (contiguous) -> out T [N,H/pool,W/pool,nh*hd] (+ lse fp32 [N,H',W',nh])."""
+                  want_lse: bool = False, q_pooled: Optional[torch.Tensor] = None):
+    """qkv T [N,H,W,3*nh*hd] (contiguous) -> out T [N,H/pool,W/pool,nh*hd] (+ lse fp32 [N,H',W',nh]).
+    q_pooled (pool == 2 only): fp32 [N,H/2,W/2,nh*hd], the pooled queries; qkv's q columns are then not read."""
     _need_gpu(qkv, bias)
     assert qkv.dim() == 4 and qkv.is_contiguous()
     N, H, W, C3 = qkv.shape
@@ -116,6 +117,13 @@ def attention_fwd(qkv: torch.Tensor, bias: torch.Tensor, ws: int, pool: int, nh:
     out = torch.empty(N, Ho, Wo, dout, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(N, Ho, Wo, nh, dtype=torch.float32, device=qkv.device) if want_lse else None
     bias_t = bias.to(qkv.dtype) if qkv.dtype != torch.float32 else None   # dtype cast only (plumbing)
+    if q_pooled is not None:
+        _need_gpu(q_pooled)
+        assert pool == 2 and q_pooled.dtype == torch.float32 and q_pooled.is_contiguous()
+        assert tuple(q_pooled.shape) == (N, Ho, Wo, dout)
+        check(lib().lsam_attention_fwd_pooled_q(dtype_code(qkv.dtype), ptr(qkv), C3, ptr(bias), ptr(bias_t), ptr(q_pooled),
+                                                dout, ptr(out), dout, ptr(lse), N, H, W, ws, nh, hd, stream()))
+        return (out, lse) if want_lse else out
     check(lib().lsam_attention_fwd(dtype_code(qkv.dtype), ptr(qkv), C3, ptr(bias), ptr(bias_t), ptr(out), dout,
                                    ptr(lse), N, H, W, ws, pool, nh, hd, stream()))
     return (out, lse) if want_lse else out

@@ -104,6 +104,13 @@ int lsam_layernorm_bwd(int dtype, const float* dy, int lddy, const float* x, int
 int lsam_attention_fwd(int dtype, const void* qkv, int ldqkv, const float* bias, const void* bias_t,
                        void* out, int ldo, float* lse, int N, int H, int W, int ws, int pool, int nh,
                        int hd, lsam_stream_t stream);
+/* lsam_attention_fwd with pool = 2 and the pooled queries supplied: q_pooled fp32 [N*(H/2)*(W/2)][ld_qp] holds
+ * do_pool(q) (hieradet.py:25-36,69-71) in output-token order, e.g. the q columns of the qkv projection taken
+ * through lsam_linear_maxpool2x2; the q columns of qkv are then never read (they need not have been written).
+ * Same result bit for bit: the max of rounded values is the rounded max. */
+int lsam_attention_fwd_pooled_q(int dtype, const void* qkv, int ldqkv, const float* bias, const void* bias_t,
+                                const float* q_pooled, int ld_qp, void* out, int ldo, float* lse, int N, int H, int W,
+                                int ws, int nh, int hd, lsam_stream_t stream);
 
 /* Backward of the above for un-pooled windows with ws*ws <= 64 (the LoRA blocks):
  *   dout T [N,H,W,nh*hd] -> dqkv T [N,H,W, lddqkv] (q|k|v gradients of the real tokens; the

@@ -202,6 +202,23 @@ def test_attention_bwd(ops, dt, H, ws, nh):
     assert rel_err(dqkv.float(), x.grad) < tol(dt, 2e-5, 1e-2)
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("H,ws,nh", [(16, 8, 2), (32, 16, 4), (32, 4, 4), (28, 14, 8), (64, 14, 2)])
+def test_attention_fwd_with_pooled_queries(ops, dt, H, ws, nh):
+    """do_pool(q) (hieradet.py:69-71) handed in instead of being taken from qkv: every forward kernel, bit for bit;
+    the q columns of qkv are poisoned to show that they are not read."""
+    hd, N = 56, 2
+    d = nh * hd
+    qkv = rnd(N, H, H, 3 * d, seed=31).cuda().to(dt)
+    bias = (0.1 * rnd(3 * d, seed=32)).cuda()
+    want, lse_want = ops.attention_fwd(qkv, bias, ws, 2, nh, want_lse=True)
+    qp = F.max_pool2d(qkv[..., :d].float().permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).contiguous()
+    poisoned = qkv.clone()
+    poisoned[..., :d] = float("nan")
+    got, lse = ops.attention_fwd(poisoned, bias, ws, 2, nh, want_lse=True, q_pooled=qp)
+    assert torch.equal(got, want) and torch.equal(lse, lse_want)
+
+
 def test_maxpool_cast_im2col(ops):
     x = rnd(2, 8, 12, 24, seed=1)
     ref = F.max_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
