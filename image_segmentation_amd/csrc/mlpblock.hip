@@ -347,15 +347,39 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlpblock_kernel(cons
                 const float rstd = 1.0f / sqrtf(group4_sum(q) / (float)d + p.eps);
                 const int m = m0 + mt * 16 + lr;
                 bf16* rowp = xo + (size_t)min(m, M - 1) * p.ldn;
+                if (d == 16 * NTO && (p.ldn & 7) == 0) {   // kernel-uniform: full width, 16-byte rows
+                    // two column tiles per 16-byte store (store instructions, not bytes, are what the write-back costs)
 #pragma unroll
-                for (int nt = 0; nt < NTO; ++nt) {
-                    const int c0 = 16 * nt + 4 * g;
-                    if (c0 < d && m < M) {
+                    for (int nt = 0; nt + 1 < NTO; nt += 2) {
+                        f32x4 v[2];
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const int c0 = 16 * (nt + t) + 4 * g;
+                            const f32x4 gm = load4(p.gamma_n + c0), bt = load4(p.beta_n + c0);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[t][r] = (acc2[mt][nt + t][r] - mean) * rstd * gm[r] + bt[r];
+                        }
+                        store_bf16_tile_pair(rowp + 16 * nt, g, v[0], v[1], m < M);
+                    }
+                    if constexpr (NTO % 2 == 1) {
+                        const int c0 = 16 * (NTO - 1) + 4 * g;
                         const f32x4 gm = load4(p.gamma_n + c0), bt = load4(p.beta_n + c0);
                         f32x4 v;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = (acc2[mt][nt][r] - mean) * rstd * gm[r] + bt[r];
-                        store4(rowp + c0, v);
+                        for (int r = 0; r < 4; ++r) v[r] = (acc2[mt][NTO - 1][r] - mean) * rstd * gm[r] + bt[r];
+                        if (m < M) store4(rowp + c0, v);
+                    }
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < NTO; ++nt) {
+                        const int c0 = 16 * nt + 4 * g;
+                        if (c0 < d && m < M) {
+                            const f32x4 gm = load4(p.gamma_n + c0), bt = load4(p.beta_n + c0);
+                            f32x4 v;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = (acc2[mt][nt][r] - mean) * rstd * gm[r] + bt[r];
+                            store4(rowp + c0, v);
+                        }
                     }
                 }
             }
@@ -422,8 +446,8 @@ int launch_mlpblock(const MlpBlockArgs& a, hipStream_t s) {
                      aligned16(a.bias_p), LSAM_ERR_BAD_ARG, "mlpblock: pointers must be 16-byte aligned");
     if (a.xn_next)
         LSAM_REQUIRE(a.gamma_n && a.beta_n && a.ldn >= a.d && a.ldn % 4 == 0 && aligned16(a.gamma_n) && aligned16(a.beta_n) &&
-                         (reinterpret_cast<uintptr_t>(a.xn_next) & 7) == 0,
-                     LSAM_ERR_BAD_ARG, "mlpblock: next-LayerNorm output needs gamma, beta, 8-byte alignment and ldn %% 4 == 0");
+                         (reinterpret_cast<uintptr_t>(a.xn_next) & 15) == 0,
+                     LSAM_ERR_BAD_ARG, "mlpblock: next-LayerNorm output needs gamma, beta, 16-byte alignment and ldn %% 4 == 0");
     switch (mlp_variant(a.d)) {
         case 0: return launch_mlp<2, 4, 2, 4>(a, s);
         case 1: return launch_mlp<4, 7, 2, 4>(a, s);
