@@ -41,7 +41,7 @@ typedef __attribute__((address_space(3))) const char* tail_lds_cp;
 #define TAIL_INTERLEAVE 1
 #endif
 #ifndef TAIL_DMA_FRAC
-#define TAIL_DMA_FRAC 1
+#define TAIL_DMA_FRAC 4   // whole step, A/B on one box: 1 -> 859, 2 -> 861, 4 -> 862 frames/s
 #endif
 // number of leading fragment batches (of nb) that carry the chunk's DMA pieces
 constexpr int DMAB(int nb) { return nb / TAIL_DMA_FRAC > 0 ? nb / TAIL_DMA_FRAC : 1; }
@@ -444,6 +444,11 @@ __global__ __launch_bounds__(64 * NW, WPC) void tailblock_kernel(const TailBlock
 // Pipeline per wave and iteration c (one barrier each): fc1 partial of chunk c | GELU of chunk c-1 from the
 // exchanged partials | fc2 of chunk c-2.  The three are independent, so with two waves per SIMD the hardware
 // overlaps one wave's VALU/LDS time with the other's MFMAs.
+// wave-pair kernel: fraction of a chunk's fragment batches that carry the next chunk's DMA pieces (see DMAB)
+#ifndef PAIR_DMA_FRAC
+#define PAIR_DMA_FRAC 2   // whole step, A/B/A/B on one box: 1 -> 862.7, 2 -> 869.2, 4 -> 866.4 frames/s
+#endif
+constexpr int PDMAB(int nb) { return nb / PAIR_DMA_FRAC > 0 ? nb / PAIR_DMA_FRAC : 1; }
 #ifndef PAIR_BSP
 #define PAIR_BSP 4
 #endif
@@ -655,7 +660,7 @@ __global__ __launch_bounds__(512) void tailpair_kernel(const TailBlockArgs p) {
                     constexpr int b = decltype(b_)::value;
                     lds_wait();
                     if constexpr (b + 1 < NBP) lds_frags<(b + 1) * BS, BS>(base, w[(b + 1) & 1]);
-                    issue_part(b_, std::integral_constant<int, NBP>{}, pc + 1, buf ^ 1);   // pc + 1 <= NPC < nck
+                    if constexpr (b < PDMAB(NBP)) issue_part(b_, std::integral_constant<int, PDMAB(NBP)>{}, pc + 1, buf ^ 1);   // pc + 1 <= NPC < nck
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < BS; ++i) {
@@ -724,7 +729,7 @@ __global__ __launch_bounds__(512) void tailpair_kernel(const TailBlockArgs p) {
                 constexpr int b = decltype(b_)::value;
                 lds_wait();
                 if constexpr (b + 1 < NB) lds_frags<(b + 1) * BS, BS>(base, w[(b + 1) & 1]);
-                issue_part(b_, std::integral_constant<int, NB>{}, next_ck, buf ^ 1);
+                if constexpr (b < PDMAB(NB)) issue_part(b_, std::integral_constant<int, PDMAB(NB)>{}, next_ck, buf ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (b == 0) {   // fc2 operand of chunk c - 2: own half in k-slots 0..3, the partner's in 4..7
 #pragma unroll
