@@ -453,7 +453,7 @@ constexpr int PDMAB(int nb) { return nb / PAIR_DMA_FRAC > 0 ? nb / PAIR_DMA_FRAC
 #define PAIR_BSP 4
 #endif
 #ifndef PAIR_BSM
-#define PAIR_BSM 4
+#define PAIR_BSM 2   // whole step, A/B on one box (with PAIR_DMA_FRAC 2): 4 -> 870, 2 -> 876, 1 -> 872 frames/s
 #endif
 template <int KS, int NTO> struct PairImg {
     static_assert(KS % 2 == 0 && NTO == 2 * KS, "pair split needs an even number of k-steps");
