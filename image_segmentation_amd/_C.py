@@ -89,6 +89,10 @@ def lib() -> C.CDLL:
         L.lsam_cast.argtypes = [i, vp, i, vp, i, i, i, vp]
         L.lsam_im2col_patch.argtypes = [i, vp, vp, i, i, i, vp]
         L.lsam_outer_reduce.argtypes = [i, vp, i, vp, i, i, i, i, vp, l, l, vp, vp]
+        L.lsam_outer_reduce_static.argtypes = [i, vp, i, vp, i, i, i, i, vp, l, l, vp]
+        L.lsam_outer_reduce_static_max_ws.restype = C.c_size_t
+        L.lsam_outer_reduce_static_max_ws.argtypes = []
+        L.lsam_outer_reduce_static_init.argtypes = []
         for name in ("lsam_window_block_image_bytes", "lsam_window_block_bias_floats",
                      "lsam_mlp_block_image_bytes", "lsam_mlp_block_bias_floats",
                      "lsam_tail_block_image_bytes", "lsam_tail_block_vec_floats", "lsam_patch_embed_image_bytes"):
@@ -144,4 +148,5 @@ EXPORTED = [
     "lsam_mlp_block_fwd", "lsam_tail_block_image_bytes", "lsam_tail_block_vec_floats", "lsam_tail_block_pack",
     "lsam_tail_block_fwd", "lsam_patch_embed_image_bytes", "lsam_patch_embed_pack", "lsam_patch_embed_fwd", "lsam_linear_maxpool2x2",
     "lsam_lateral_conv_image_bytes", "lsam_lateral_conv_pack", "lsam_lateral_conv_fwd", "lsam_mlp_block_fwd_next_norm", "lsam_attention_fwd_pooled_q",
+    "lsam_outer_reduce_static_max_ws", "lsam_outer_reduce_static_init", "lsam_outer_reduce_static",
 ]

@@ -215,4 +215,17 @@ int lsam_outer_reduce(int dtype, const void* X, int ldx, const void* Y, int ldy,
                                        out_cs, out_ks, partial, s));
 }
 
+size_t lsam_outer_reduce_static_max_ws(void) { return outer_reduce_static_max_bytes(); }
+int lsam_outer_reduce_static_init(void) { return outer_reduce_static_init(); }
+int lsam_outer_reduce_static(int dtype, const void* X, int ldx, const void* Y, int ldy, int M, int C, int R, float* out,
+                             long out_cs, long out_ks, lsam_stream_t stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    LSAM_REQUIRE(X && Y && out, LSAM_ERR_BAD_ARG, "outer_reduce_static: null operand");
+    DISPATCH(dtype,
+             launch_outer_reduce_static<float>(static_cast<const float*>(X), ldx, static_cast<const float*>(Y), ldy, M, C,
+                                               R, out, out_cs, out_ks, s),
+             launch_outer_reduce_static<bf16>(static_cast<const bf16*>(X), ldx, static_cast<const bf16*>(Y), ldy, M, C, R,
+                                              out, out_cs, out_ks, s));
+}
+
 }  // extern "C"

@@ -147,5 +147,11 @@ template <typename T> int launch_outer_reduce4(const OuterJobs& j, int M, int C,
 template <typename T>
 int launch_outer_reduce(const T* X, int ldx, const T* Y, int ldy, int M, int C, int R, float* out,
                         long out_cs, long out_ks, void* partial, hipStream_t s);
+// the same with the partial sums in a library-owned static device array (no caller workspace, no allocation)
+size_t outer_reduce_static_max_bytes();
+int outer_reduce_static_init();
+template <typename T>
+int launch_outer_reduce_static(const T* X, int ldx, const T* Y, int ldy, int M, int C, int R, float* out,
+                               long out_cs, long out_ks, hipStream_t s);
 
 }  // namespace lsam

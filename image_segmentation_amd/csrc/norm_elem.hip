@@ -1,6 +1,8 @@
 // HBM-bound kernels of the path: LayerNorm forward/backward (one row per 32- or 64-lane group,
 // float4 accesses, xor-shuffle reductions), 2x2 max-pool of the shortcut, casts, PatchEmbed
 // im2col, and the LoRA dA/dB token reductions.
+#include <mutex>
+
 #include "kernels.hpp"
 
 namespace lsam {
@@ -476,5 +478,58 @@ template int launch_outer_reduce4<bf16>(const OuterJobs&, int, int, int, void*, 
 
 template int launch_outer_reduce<float>(const float*, int, const float*, int, int, int, int, float*, long, long, void*, hipStream_t);
 template int launch_outer_reduce<bf16>(const bf16*, int, const bf16*, int, int, int, int, float*, long, long, void*, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------
+// launch_outer_reduce for callers that cannot allocate (code under HIP-graph capture, tight serving
+// loops): the fp32 partial sums live in a file-scope device array instead of a caller workspace.
+// Every GPU the library runs on holds its own copy of `scratch` (OR_STATIC_BYTES) until the process
+// ends.  In host code the NAME `scratch` is only a handle for hipGetSymbolAddress, never a device
+// address: the per-device address is resolved once, with that device current, and from then on
+// only that pointer is handed to kernels.  Pass 1 overwrites every partial pass 2 reads, so nothing
+// has to be cleared between calls; calls that overlap on one GPU (two streams) race on the array.
+// ---------------------------------------------------------------------------------------------
+constexpr size_t OR_STATIC_BYTES = size_t(8) << 20;
+static __device__ __align__(256) float scratch[OR_STATIC_BYTES / sizeof(float)];
+constexpr int OR_MAX_DEVICES = 64;
+static std::mutex g_scratch_mu;
+static float* g_scratch_ptr[OR_MAX_DEVICES] = {};
+
+size_t outer_reduce_static_max_bytes() { return OR_STATIC_BYTES; }
+
+static int scratch_of_current_device(float** out) {
+    int dev = -1;
+    LSAM_HIP(hipGetDevice(&dev));
+    LSAM_REQUIRE(dev >= 0 && dev < OR_MAX_DEVICES, LSAM_ERR_UNSUPPORTED, "outer_reduce_static: device index %d", dev);
+    std::lock_guard<std::mutex> g(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        LSAM_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        LSAM_REQUIRE(p, LSAM_ERR_HIP, "outer_reduce_static: hipGetSymbolAddress returned null on device %d", dev);
+        g_scratch_ptr[dev] = static_cast<float*>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return LSAM_OK;
+}
+
+int outer_reduce_static_init() {
+    float* p = nullptr;
+    return scratch_of_current_device(&p);
+}
+
+template <typename T>
+int launch_outer_reduce_static(const T* X, int ldx, const T* Y, int ldy, int M, int C, int R, float* out, long out_cs,
+                               long out_ks, hipStream_t s) {
+    LSAM_REQUIRE(M > 0 && C > 0, LSAM_ERR_BAD_ARG, "outer_reduce_static: null/empty");
+    const size_t need = outer_reduce_ws(M, C);
+    LSAM_REQUIRE(need <= OR_STATIC_BYTES, LSAM_ERR_WORKSPACE,
+                 "outer_reduce_static: M=%d, C=%d needs %zu bytes of partial sums, the built-in scratch holds %zu "
+                 "(ceil(M/128)*C*64 <= 8 MiB); use lsam_outer_reduce with a caller workspace",
+                 M, C, need, OR_STATIC_BYTES);
+    float* part = nullptr;
+    LSAM_TRY(scratch_of_current_device(&part));
+    return launch_outer_reduce<T>(X, ldx, Y, ldy, M, C, R, out, out_cs, out_ks, part, s);
+}
+template int launch_outer_reduce_static<float>(const float*, int, const float*, int, int, int, int, float*, long, long, hipStream_t);
+template int launch_outer_reduce_static<bf16>(const bf16*, int, const bf16*, int, int, int, int, float*, long, long, hipStream_t);
 
 }  // namespace lsam

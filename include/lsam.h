@@ -174,6 +174,20 @@ size_t lsam_outer_reduce_ws(int M, int C);
 int lsam_outer_reduce(int dtype, const void* X, int ldx, const void* Y, int ldy, int M, int C, int R,
                       float* out, long out_cs, long out_ks, void* partial, lsam_stream_t stream);
 
+/* lsam_outer_reduce WITHOUT a caller workspace and without any allocation.  No counterpart in the reference: it
+ * exists for callers that cannot allocate device memory (code under HIP-graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  The fp32 partial sums of pass 1 live in a static device array inside liblsam.so
+ * (lsam_outer_reduce_static_max_ws() bytes = 8 MiB, held on every GPU the library runs on until the process ends);
+ * M, C with lsam_outer_reduce_ws(M, C) beyond that are rejected with LSAM_ERR_WORKSPACE (the LoRA blocks of the
+ * path, M = 16 frames x 1024 tokens, C = 896, need 7.0 MiB).  Same kernels, same result bit for bit as
+ * lsam_outer_reduce.  The array's per-device address is resolved once per device (hipGetSymbolAddress) on the
+ * first call there, or by lsam_outer_reduce_static_init() with that device current -- call that before a stream
+ * capture begins.  All calls on one GPU share the array: calls that overlap there (different streams) race. */
+size_t lsam_outer_reduce_static_max_ws(void);
+int lsam_outer_reduce_static_init(void);
+int lsam_outer_reduce_static(int dtype, const void* X, int ldx, const void* Y, int ldy, int M, int C, int R,
+                             float* out, long out_cs, long out_ks, lsam_stream_t stream);
+
 /* Fused attention half of a same-width 8x8-window block, bf16 MFMA, in one kernel:
  *   y = x + proj(attn(qkv(LayerNorm1(x))))       (MultiScaleBlock.forward, hieradet.py:134-163 with
  *   window_partition/unpartition, backbones/utils.py:16-60, and MultiScaleAttention.forward,
