@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
-"""Throughput of the LoRA-SAM2 Hiera-B+ image-encoder fwd+bwd hot path on MI355X.
+"""Throughput of the LoRA-SAM2 Hiera image-encoder hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config 1|3|4]
   (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One step = one pass of the hot path over one batch of synthetic frames already resident in
-HBM: encoder forward (trunk + FPN neck) under bf16, loss = sum_l mean(fpn_l^2), backward to
-the LoRA A/B factors, mean all-reduce of the LoRA gradients (N>1), AdamW step on them.
-Workload = BASELINE.json configs[1]: sam2.1_hiera_base_plus + LoRA_qkv r=4, bf16, batch 16 per
-GPU (weak scaling: configs[2] is 16 x 8 = 128).  Prints ONE JSON line on rank 0.
+--config 1 (default; BASELINE.json configs[1], and configs[2] under --gpus 8): sam2.1_hiera_base_plus + LoRA_qkv r=4,
+    bf16 fwd+bwd, 16 frames of 1024^2 per GPU.  One step = encoder forward (trunk + FPN neck), loss = sum_l mean(fpn_l^2),
+    backward to the LoRA A/B factors, mean all-reduce of the LoRA gradients (N>1), AdamW step on them.
+--config 3 (configs[3]): sam2.1_hiera_large + LoRA_qkv r=8, bf16 encoder-only inference (trunk + neck under no_grad),
+    64 frames per GPU.  One step = one batch.
+--config 4 (configs[4]): train_cl_kmean-style feature extraction: Hiera-B+ + LoRA r=4, Hiera.get_embedding + per-frame
+    spatial mean of the stage-4 map (896-d), 10,000 frames sharded by frame over the ranks (features.shard_range), batches
+    of 64.  One step = one batch; without --steps the pass covers all 10,000 frames.
+Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -26,21 +30,41 @@ import torch.distributed as dist
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-GF_PER_FRAME = 657.4e9       # algorithmic fwd+bwd FLOPs, Hiera-B+ r=4 @1024^2
 PEAK_BF16_TFLOPS = 2500.0    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0        # HBM3E spec (same table; ~6.3 TB/s is what a streaming copy achieves)
 BPLUS = dict(embed_dim=112, num_heads=2)
-# dominant kernel of the step (rocprofv3 --kernel-trace --stats, profiles/): the fused block tail of the
-# sixteen 448-wide stage-3 blocks (tailblock.hip).  liblsam tags its live event records with 9000 + d.
-DOMINANT_CFG = 9448
-DOMINANT_KERNEL = ("lsam::tailpair_kernel<14, 28> (proj + residual + LN2 + fc1 + GELU + fc2 + residual + "
-                   "next LN1, 448 wide; algorithmic FLOPs 18 M d^2 per launch)")
+LARGE = dict(embed_dim=144, num_heads=2, stages=(2, 6, 36, 4), global_att_blocks=(23, 33, 43), window_spec=(8, 4, 16, 8))
+# algorithmic FLOPs per 1024^2 frame
+GF_BPLUS_FWD_BWD = 657.4e9   # Hiera-B+ r=4 forward + LoRA backward
+GF_BPLUS_FWD = 621.3e9       # forward incl. neck (7.05 GF); the trunk-only extraction pass is 614.2
+GF_BPLUS_TRUNK = 614.2e9
+GF_LARGE_FWD = 1821.4e9      # Hiera-L r=8 forward incl. neck
+
+# live per-launch records of liblsam (lsam_prof_arm/read): cfg id -> (name, unit of `work`)
+KERNEL_NAMES = {
+    9448: ("tailpair<14,28> stage-3 block tail (proj+res+LN2+MLP+res+next LN1, 448 wide)", "flop"),
+    9224: ("tail<7,14> stage-2 block tail (224 wide)", "flop"),
+    2224: ("gemm3 256x224 persistent bf16 GEMM, bf16 out", "flop"),
+    2225: ("gemm3 256x224 persistent bf16 GEMM, fp32 out", "flop"),
+    2112: ("gemm2 256x112-tile bf16 GEMM, bf16 out (N % 224 != 0)", "flop"),
+    2113: ("gemm2 256x112-tile bf16 GEMM, fp32 out", "flop"),
+    2128: ("gemm_cfg 128-wide-tile bf16 GEMM (N % 112 != 0: Hiera-L widths, LoRA u columns)", "flop"),
+    4128: ("gemm_cfg 128-wide-tile fp32 GEMM", "flop"),
+    5000: ("global attention (attn2_fwd)", "flop"),
+    5001: ("window attention (attnw / attn2 / attn_fwd)", "flop"),
+    5002: ("attention backward (LoRA blocks)", "flop"),
+    100: ("ln_fwd", "byte"), 101: ("ln_bwd", "byte"), 102: ("cast fp32->bf16", "byte"),
+    103: ("lateral 1x1 conv (levels 0/1)", "byte"), 104: ("patch_embed 7x7/4 conv + pos", "byte"),
+    105: ("winblock stage-1 attention half", "byte"), 106: ("mlpblock stage-1 MLP half", "byte"),
+    107: ("maxpool2x2", "byte"), 108: ("spatial_mean", "byte"), 109: ("LoRA dA/dB token reductions", "byte"),
+    110: ("neck level (lateral + top-down add + NCHW store)", "byte"),
+}
 
 
-def measured_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/<round>/traffic.json, written by tools/pmc_traffic.py from separate FETCH_SIZE and
-    WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py
-    cannot run the counter passes on itself; null when the file is absent."""
+def measured_traffic(kernel_key: str):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/<round>/traffic.json, written by
+    tools/pmc_traffic.py from separate FETCH_SIZE and WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950).  bench.py cannot run the counter passes on itself; null when absent."""
     best = None
     root = os.path.join(REPO, "profiles")
     if os.path.isdir(root):
@@ -52,15 +76,19 @@ def measured_traffic():
         return None
     try:
         with open(best) as fh:
-            return json.load(fh).get("hbm_bytes_per_launch")
+            j = json.load(fh)
     except (OSError, ValueError):
         return None
+    per = j.get("per_kernel", {})
+    if kernel_key in per:
+        return per[kernel_key]
+    return j.get("hbm_bytes_per_launch") if kernel_key == j.get("kernel_key", "tailpair") else None
 
 
-def build(device, rank_seed=0, lora_rank=4):
+def build(device, cfg=BPLUS, lora_rank=4):
     import image_segmentation_amd as m
     from image_segmentation_amd.synth import fill_synthetic_, synth_tensor
-    enc = m.build_image_encoder(dict(BPLUS))
+    enc = m.build_image_encoder(dict(cfg))
     fill_synthetic_(enc, 0)
     m.wrap_image_encoder_lora(types.SimpleNamespace(image_encoder=enc), lora_rank)
     with torch.no_grad():
@@ -78,41 +106,89 @@ def fpn_loss(out):
     return sum(torch.linalg.vector_norm(f, dtype=torch.float32) ** 2 / f.numel() for f in out["backbone_fpn"])
 
 
-def cpu_baseline(iters: int):
-    """The oracle (CPU restatement of the reference path, pinned to reference goldens) timed on
-    this box's host cores: configs[0] = B+ r=4, batch 1, fp32, one 1024^2 frame, fwd+bwd."""
+def cpu_baseline(config: int, warm: int, iters: int):
+    """The oracle (CPU restatement of the reference path, pinned to reference goldens; kind "port") timed on this box's
+    host cores on a bounded sample of the same workload: batch 1, fp32, one 1024^2 frame per iteration."""
     from image_segmentation_amd.synth import synth_frames
     from oracle import hiera_oracle as O
     from oracle.params import make_params
-    cores = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(cores)
-    spec = O.block_specs(**BPLUS)
-    p = make_params(spec, 4, 0)
+    cores = torch.get_num_threads()      # the box's OMP_NUM_THREADS share (16 on a 1-GPU box), not the machine's CPU count
+    cfg, rank = (LARGE, 8) if config == 3 else (BPLUS, 4)
+    spec = O.block_specs(**cfg)
+    p = make_params(spec, rank, 0)
     img = synth_frames(1, 1024, 0)
+    tp = {k[len("trunk."):]: v for k, v in p.items() if k.startswith("trunk.")}
 
-    def it():
-        for t in p.values():
-            t.grad = None
-        loss = O.fpn_loss(O.image_encoder_forward(p, img, spec))
-        loss.backward()
+    if config == 1:
+        what = "fwd+bwd (configs[0])"
 
-    it()
+        def it():
+            for t in p.values():
+                t.grad = None
+            O.fpn_loss(O.image_encoder_forward(p, img, spec)).backward()
+    elif config == 3:
+        what = "encoder forward, no grad"
+
+        def it():
+            with torch.no_grad():
+                O.image_encoder_forward(p, img, spec)
+    else:
+        what = "get_embedding + spatial mean, no grad"
+
+        def it():
+            with torch.no_grad():
+                O.trunk_forward(tp, img, spec, n_grad_blocks=0)[-1].mean(dim=(2, 3))
+
+    for _ in range(warm):
+        it()
     t0 = time.perf_counter()
     for _ in range(iters):
         it()
     dt = time.perf_counter() - t0
-    return {"value": round(iters / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{iters} timed fwd+bwd iterations (1 warm-up) of configs[0]: B+ r=4, batch 1, "
-                      f"fp32, one 1024x1024 frame, torch CPU kernels on {cores} threads"}
+    name = "Hiera-L r=8" if config == 3 else "Hiera-B+ r=4"
+    return {"value": round(iters / dt, 4), "unit": "frames/s", "cores": cores, "host_cpu_count": os.cpu_count(),
+            "kind": "port",
+            "sample": f"{iters} timed iterations ({warm} warm-up) of {name} {what}, batch 1, fp32, one 1024x1024 frame, "
+                      f"torch CPU kernels on {cores} threads"}
+
+
+def kernel_table(psteps: int):
+    """Per-kernel-class live timing (HIP events on the launch stream, recorded inside liblsam) of `psteps` steps."""
+    from image_segmentation_amd import _C
+    cap = 600 * psteps
+    ms = (C.c_float * cap)()
+    wk = (C.c_double * cap)()
+    cfg = (C.c_int * cap)()
+    n = _C.lib().lsam_prof_read(cap, ms, wk, cfg, None)
+    agg = {}
+    for i in range(n):
+        a = agg.setdefault(cfg[i], [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += ms[i]
+        a[2] += wk[i]
+    rows = []
+    for c, (cnt, tms, twk) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        name, unit = KERNEL_NAMES.get(c, (f"cfg {c}", "flop" if c >= 1000 else "byte"))
+        rate = twk / max(tms * 1e-3, 1e-12)
+        row = {"cfg": c, "kernel": name, "launches_per_step": round(cnt / psteps, 2), "ms_per_step": round(tms / psteps, 3),
+               "avg_launch_us": round(1e3 * tms / cnt, 2)}
+        if unit == "flop":
+            row.update(achieved=round(rate / 1e12, 1), unit="TFLOP/s", frac=round(rate / 1e12 / PEAK_BF16_TFLOPS, 4))
+        else:
+            row.update(achieved=round(rate / 1e9, 1), unit="GB/s", frac=round(rate / 1e9 / PEAK_HBM_GBS, 4))
+        rows.append(row)
+    return rows, agg
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="frames per GPU")
-    ap.add_argument("--cpu-iters", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=1, choices=(1, 3, 4), help="BASELINE.json configs[] index")
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU and step")
+    ap.add_argument("--frames", type=int, default=10000, help="config 4: frames in the whole pass")
+    ap.add_argument("--cpu-iters", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -129,100 +205,135 @@ def main():
 
     from image_segmentation_amd import _C
     from image_segmentation_amd.dp import LoRAGradReducer
+    from image_segmentation_amd.features import extract_batch, shard_range
     from image_segmentation_amd.synth import synth_frames_device
 
-    enc = build(device)
-    lora = [p for p in enc.parameters() if p.requires_grad]
-    reducer = LoRAGradReducer(lora).attach(enc.trunk)   # per-block buckets, all-reduce overlapped with backward
-    reducer.broadcast_params(0)
-    opt = torch.optim.AdamW(lora, lr=1e-4)   # config.yaml:6 of the reference
-    B = args.batch
-    img = synth_frames_device(B, 1024, 0, device, first_index=rank * B)   # resident before timing
+    config = args.config
+    B = args.batch or {1: 16, 3: 64, 4: 64}[config]
+    warmup = args.warmup if args.warmup is not None else {1: 5, 3: 2, 4: 3}[config]
 
-    def step():
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            out = enc(img)
-        loss = fpn_loss(out)
-        loss.backward()
-        reducer.reduce()
-        opt.step()
-        opt.zero_grad(set_to_none=True)
-        return loss
+    if config == 1:
+        enc = build(device)
+        lora = [p for p in enc.parameters() if p.requires_grad]
+        reducer = LoRAGradReducer(lora).attach(enc.trunk)   # per-block buckets, all-reduce overlapped with backward
+        reducer.broadcast_params(0)
+        opt = torch.optim.AdamW(lora, lr=1e-4)   # config.yaml:6 of the reference
+        img = synth_frames_device(B, 1024, 0, device, first_index=rank * B)   # resident before timing
+        steps = args.steps if args.steps is not None else 20
+        frames_per_step = B
+        gf_per_frame = GF_BPLUS_FWD_BWD
+
+        def step(i):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = enc(img)
+            loss = fpn_loss(out)
+            loss.backward()
+            reducer.reduce()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            return loss
+    elif config == 3:
+        enc = build(device, LARGE, 8)
+        img = synth_frames_device(B, 1024, 0, device, first_index=rank * B)
+        steps = args.steps if args.steps is not None else 5
+        frames_per_step = B
+        gf_per_frame = GF_LARGE_FWD
+
+        def step(i):
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                out = enc(img)
+            return out["vision_features"].float().abs().max()
+    else:
+        enc = build(device)
+        lo, hi = shard_range(args.frames, rank, world)       # this rank's slice of the 10,000 frames: no data-path collective
+        pool_n = 4 * B                                        # resident pool of distinct frames, cycled through the pass
+        pool = synth_frames_device(pool_n, 1024, 0, device, first_index=rank * pool_n)
+        steps = args.steps if args.steps is not None else (hi - lo + B - 1) // B
+        frames_per_step = B
+        gf_per_frame = GF_BPLUS_TRUNK
+        feats = torch.empty(steps * B, enc.trunk.channel_list[0], dtype=torch.float32, device=device)
+
+        def source(first, n):
+            o = first % pool_n
+            return pool[o:o + n] if o + n <= pool_n else torch.cat([pool[o:], pool[: n - (pool_n - o)]])
+
+        def step(i):
+            f = extract_batch(enc.trunk, source(lo + i * B, B))
+            feats[i * B:(i + 1) * B] = f
+            return f[0, 0]
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(warmup):
+        step(i)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
+    for i in range(steps):
+        last = step(i)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert torch.isfinite(loss).item(), "non-finite loss"
-    fps = world * B * args.steps / elapsed
+    assert torch.isfinite(last).item(), "non-finite result"
+    fps = world * frames_per_step * steps / elapsed
 
     roofline = None
+    kernels = None
     if rank == 0:
-        # live per-launch timing of the dominant kernel (gemm3_kernel<false, false>: the persistent
-        # 256x224-tile bf16 MFMA GEMM with bf16 output that runs most block linears): HIP events on
-        # the launch stream, recorded inside liblsam (cfg 2224), over `psteps` further steps of the
-        # same workload.  achieved = algorithmic 2*M*N*K FLOPs of those launches / their duration.
-        psteps = min(3, args.steps)
-        cap = 400 * psteps
-        _C.check(_C.lib().lsam_prof_arm(cap))
-        for _ in range(psteps):
-            step()
+        # live per-launch timing of every liblsam kernel class: HIP events on the launch stream, recorded inside the
+        # library, over `psteps` further steps of the same workload.  achieved = algorithmic FLOPs (or HBM bytes) of
+        # those launches / their duration.
+        psteps = min(2, steps)
+        _C.check(_C.lib().lsam_prof_arm(600 * psteps))
+        for i in range(psteps):
+            step(i)
         torch.cuda.synchronize()
-        ms = (C.c_float * cap)()
-        fl = (C.c_double * cap)()
-        cfg = (C.c_int * cap)()
-        n = _C.lib().lsam_prof_read(cap, ms, fl, cfg, None)
-        sel = [i for i in range(n) if cfg[i] == DOMINANT_CFG]
-        all_ms = sum(ms[i] for i in range(n))
-        tot_ms = sum(ms[i] for i in sel)
-        tot_fl = sum(fl[i] for i in sel)
-        achieved = tot_fl / (tot_ms * 1e-3) / 1e12
-        gemm = [i for i in range(n) if cfg[i] == 2224]
-        gemm_tf = sum(fl[i] for i in gemm) / max(1e-9, sum(ms[i] for i in gemm) * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": DOMINANT_KERNEL,
-                    "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": measured_traffic(),
-                    "launches_per_step": len(sel) // psteps,
-                    "avg_launch_us": round(1e3 * tot_ms / max(1, len(sel)), 2),
-                    "avg_launch_gflop": round(tot_fl / max(1, len(sel)) / 1e9, 3),
-                    "algorithmic_hbm_bytes_per_launch": 12 * B * 64 * 64 * 448,
-                    "kernel_ms_per_step": round(tot_ms / psteps, 3),
-                    "second_kernel": {"kernel": "lsam::gemm3_kernel<false, false> (256x224 persistent bf16 GEMM)",
-                                      "achieved": round(gemm_tf, 2), "launches_per_step": len(gemm) // psteps,
-                                      "kernel_ms_per_step": round(sum(ms[i] for i in gemm) / psteps, 3)},
-                    "all_timed_mfma_ms_per_step": round(all_ms / psteps, 3)}
+        kernels, agg = kernel_table(psteps)
+        mfma_rows = [r for r in kernels if r["unit"] == "TFLOP/s"]
+        dom = max(mfma_rows, key=lambda r: r["ms_per_step"])
+        cnt, tms, twk = agg[dom["cfg"]]
+        traffic_key = {9448: "tailpair", 9224: "tail224", 2224: "gemm3"}.get(dom["cfg"], str(dom["cfg"]))
+        roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": dom["frac"], "traffic": measured_traffic(traffic_key),
+                    "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"],
+                    "avg_launch_gflop": round(twk / cnt / 1e9, 3), "kernel_ms_per_step": dom["ms_per_step"],
+                    "all_timed_kernel_ms_per_step": round(sum(r["ms_per_step"] for r in kernels), 3)}
+        if dom["cfg"] == 9448:
+            roofline["algorithmic_hbm_bytes_per_launch"] = 12 * B * 64 * 64 * 448
     if world > 1:
         dist.barrier()
 
     if rank == 0:
+        model = "sam2.1_hiera_large + LoRA_qkv r=8" if config == 3 else "sam2.1_hiera_base_plus + LoRA_qkv r=4"
+        what = {1: "bf16 fwd+bwd (+LoRA-grad all-reduce, AdamW)",
+                3: "bf16 encoder-only inference (trunk + FPN neck, no grad)",
+                4: f"bf16 feature extraction (get_embedding + per-frame spatial mean), {steps * B * world} frames "
+                   f"sharded by frame"}[config]
+        metric = {1: "frames/sec LoRA-SAM2 Hiera-B+ fwd+bwd @1024^2",
+                  3: "frames/sec LoRA-SAM2 Hiera-L encoder-only inference @1024^2",
+                  4: "frames/sec LoRA-SAM2 Hiera-B+ feature-extraction pass @1024^2"}[config]
         line = {
-            "metric": "frames/sec LoRA-SAM2 Hiera-B+ fwd+bwd @1024^2",
-            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "metric": metric, "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": round(1e3 * elapsed / steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-            "data": "synthetic N(0,1) frames generated on-device; seeded synthetic weights (no checkpoints offline)",
-            "config": {"workload": "BASELINE.json configs[1]: sam2.1_hiera_base_plus + LoRA_qkv r=4, bf16 "
-                                   "fwd+bwd (+LoRA-grad all-reduce, AdamW), 1024x1024",
+            "data": "synthetic N(0,1) frames generated on-device before the timed region"
+                    + (f" (a resident pool of {4 * B} distinct frames cycled through the pass)" if config == 4 else "")
+                    + "; seeded synthetic weights (no checkpoints offline)",
+            "config": {"workload": f"BASELINE.json configs[{config}]: {model}, {what}, 1024x1024",
                        "frames_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "residual_stream": "fp32"},
-            "mfma_frac_whole_step": round(fps / world * GF_PER_FRAME / (PEAK_BF16_TFLOPS * 1e12), 4),
+            "mfma_frac_whole_step": round(fps / world * gf_per_frame / (PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": roofline,
+            "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_iters)
+            iters = args.cpu_iters if args.cpu_iters is not None else {1: 10, 3: 4, 4: 10}[config]
+            line["cpu_baseline"] = cpu_baseline(config, 3 if config != 3 else 1, iters)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

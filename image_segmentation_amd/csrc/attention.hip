@@ -895,6 +895,9 @@ template <typename T> int launch_attn_fwd(const AttnArgs& a, hipStream_t s) {
     LSAM_REQUIRE(a.nh <= 65535, LSAM_ERR_UNSUPPORTED, "attention: too many heads");
     const WinGeom G = make_geom(a.H, a.W, a.ws, a.pool);
     const int max_nq = G.qh * G.qw;
+    // algorithmic FLOPs: every real query against all keys of its window (pad-token keys included), QK^T + PV
+    ProfScope ps(s, 4.0 * a.N * (a.H / a.pool) * (a.W / a.pool) * (double)(G.wsh * G.wsw) * a.nh * a.hd,
+                 a.ws == 0 ? PROF_ATTN_GLOBAL : PROF_ATTN_WIN, a.N * (a.H / a.pool) * (a.W / a.pool), G.wsh * G.wsw, a.nh * a.hd);
     if constexpr (sizeof(T) == 2) {
         if (a.bias_t && a.hd <= 64 && a.ws > 0 && G.wsh * G.wsw > 64 && G.wsh * G.wsw <= 208 && max_nq > 64 && a.ldqkv % 8 == 0)
             return attnw_launch(a, s);   // (pooled windows have few queries per staged K/V tile: the streaming kernel below)

@@ -24,6 +24,22 @@ int prof_arm(int capacity);
 int prof_read(int max, float* ms, double* flops, int* cfg, int* mnk);
 int prof_begin(hipStream_t s);   // live HIP-event timing of one launch while armed (bench.py's roofline)
 void prof_end(int rec, hipStream_t s, double flops, int cfg, int m, int n, int k);
+// RAII form: brackets everything launched on `s` within the scope.  `work` = algorithmic FLOPs for MFMA-bound kernels
+// (cfg >= 1000) and algorithmic HBM BYTES for the HBM-bound ones (cfg < 1000).  Scopes must not nest.
+enum {
+    PROF_LN_FWD = 100, PROF_LN_BWD = 101, PROF_CAST = 102, PROF_LATERAL = 103, PROF_PATCH_EMBED = 104, PROF_WINBLOCK = 105,
+    PROF_MLPBLOCK = 106, PROF_MAXPOOL = 107, PROF_SPATIAL_MEAN = 108, PROF_OUTER = 109, PROF_NECK = 110,
+    PROF_ATTN_SMALL = 111,                                      /* windows with <= 16 queries per wave: bytes */
+    PROF_ATTN_GLOBAL = 5000, PROF_ATTN_WIN = 5001, PROF_ATTN_BWD = 5002   /* FLOPs */
+};
+struct ProfScope {
+    int rec; hipStream_t s; double work; int cfg, m, n, k;
+    ProfScope(hipStream_t s_, double work_, int cfg_, int m_, int n_, int k_)
+        : rec(prof_begin(s_)), s(s_), work(work_), cfg(cfg_), m(m_), n(n_), k(k_) {}
+    ~ProfScope() { prof_end(rec, s, work, cfg, m, n, k); }
+    ProfScope(const ProfScope&) = delete;
+    ProfScope& operator=(const ProfScope&) = delete;
+};
 
 template <typename T>
 int launch_pack_matrix(const float* src, long src_rs, long src_cs, int rows, int cols, T* dst, int ldd,

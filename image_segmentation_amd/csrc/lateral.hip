@@ -151,6 +151,7 @@ int launch_lateral(const float* x, const void* img, const float* bias, void* out
     LSAM_REQUIRE(v >= 0, LSAM_ERR_UNSUPPORTED, "lateral: K %d, N %d not supported", K, N);
     LSAM_REQUIRE(aligned16(x) && aligned16(img) && aligned16(bias) && aligned16(out), LSAM_ERR_BAD_ARG,
                  "lateral: pointers must be 16-byte aligned");
+    ProfScope ps(s, (double)M * (4.0 * K + 2.0 * N), PROF_LATERAL, M, N, K);
     if (v == 0) return launch_lat<4>(x, img, bias, static_cast<bf16*>(out), M, K, s);
     return launch_lat<7>(x, img, bias, static_cast<bf16*>(out), M, K, s);
 }

@@ -448,6 +448,7 @@ int launch_mlpblock(const MlpBlockArgs& a, hipStream_t s) {
         LSAM_REQUIRE(a.gamma_n && a.beta_n && a.ldn >= a.d && a.ldn % 4 == 0 && aligned16(a.gamma_n) && aligned16(a.beta_n) &&
                          (reinterpret_cast<uintptr_t>(a.xn_next) & 15) == 0,
                      LSAM_ERR_BAD_ARG, "mlpblock: next-LayerNorm output needs gamma, beta, 16-byte alignment and ldn %% 4 == 0");
+    ProfScope ps(s, (double)a.M * a.d * (8.0 + (a.xn_next ? 2.0 : 0.0)), PROF_MLPBLOCK, a.M, a.d, 0);   // x in + y out (+ bf16 next LN)
     switch (mlp_variant(a.d)) {
         case 0: return launch_mlp<2, 4, 2, 4>(a, s);
         case 1: return launch_mlp<4, 7, 2, 4>(a, s);

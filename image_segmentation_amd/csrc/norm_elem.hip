@@ -98,6 +98,7 @@ int launch_ln_fwd(const float* x, int ldx, const float* gamma, const float* beta
     LSAM_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(gamma) &&
                      aligned16(beta) && (reinterpret_cast<uintptr_t>(y) & 7) == 0,
                  LSAM_ERR_BAD_ARG, "layernorm: C, ld must be multiples of 4 and pointers aligned");
+    ProfScope ps(s, (double)M * C * (4 + sizeof(T)), PROF_LN_FWD, M, C, 0);
     if (C / 4 <= 32) return ln_fwd_dispatch<T, 32>(x, ldx, gamma, beta, y, ldy, stats, M, C, eps, s);
     return ln_fwd_dispatch<T, 64>(x, ldx, gamma, beta, y, ldy, stats, M, C, eps, s);
 }
@@ -190,6 +191,7 @@ int launch_ln_bwd(const float* dy, int lddy, const float* x, int ldx, const floa
     LSAM_REQUIRE(C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && (!dres || lddres % 4 == 0) &&
                      (!dx || lddx % 4 == 0) && (!dx_t || lddxt % 4 == 0),
                  LSAM_ERR_BAD_ARG, "layernorm_bwd: C and leading dimensions must be multiples of 4");
+    ProfScope ps(s, (double)M * C * (8.0 + (dres ? 4 : 0) + (dx ? 4 : 0) + (dx_t ? sizeof(T) : 0)), PROF_LN_BWD, M, C, 0);
     if (C / 4 <= 32)
         return ln_bwd_dispatch<T, 32>(dy, lddy, x, ldx, stats, gamma, dres, lddres, dx, lddx, dx_t, lddxt, M, C, s);
     return ln_bwd_dispatch<T, 64>(dy, lddy, x, ldx, stats, gamma, dres, lddres, dx, lddx, dx_t, lddxt, M, C, s);
@@ -224,6 +226,7 @@ int launch_maxpool2x2(const float* x, float* out, int N, int H, int W, int C, hi
     LSAM_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 4 == 0, LSAM_ERR_UNSUPPORTED, "maxpool: need even H,W and C%%4==0");
     const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    ProfScope ps(s, (double)N * H * W * C * 5.0, PROF_MAXPOOL, N * H * W, C, 0);
     hipLaunchKernelGGL(maxpool2x2_kernel, dim3(grid), dim3(256), 0, s, x, out, N, H, W, C / 4);
     LSAM_LAUNCH_CHECK();
     return LSAM_OK;
@@ -253,6 +256,7 @@ __global__ __launch_bounds__(256) void spatial_mean_kernel(const float* __restri
 int launch_spatial_mean(const float* x, float* out, int N, int HW, int C, hipStream_t s) {
     LSAM_REQUIRE(x && out && N > 0 && HW > 0 && C > 0, LSAM_ERR_BAD_ARG, "spatial_mean: null/empty");
     LSAM_REQUIRE(N <= 65535, LSAM_ERR_UNSUPPORTED, "spatial_mean: at most 65535 frames per call");
+    ProfScope ps(s, (double)N * HW * C * 4.0, PROF_SPATIAL_MEAN, N * HW, C, 0);
     hipLaunchKernelGGL(spatial_mean_kernel, dim3(cdiv(C, 64), N), dim3(256), 0, s, x, out, HW, C);
     LSAM_LAUNCH_CHECK();
     return LSAM_OK;
@@ -276,6 +280,7 @@ int launch_cast(const float* src, int lds, T* dst, int ldd, int rows, int cols, 
     LSAM_REQUIRE(cols % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0, LSAM_ERR_BAD_ARG, "cast: multiples of 4 required");
     const long total = (long)rows * (cols / 4);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    ProfScope ps(s, (double)rows * cols * (4 + sizeof(T)), PROF_CAST, rows, cols, 0);
     hipLaunchKernelGGL(cast_kernel<T>, dim3(grid), dim3(256), 0, s, src, lds, dst, ldd, rows, cols / 4);
     LSAM_LAUNCH_CHECK();
     return LSAM_OK;
@@ -465,6 +470,7 @@ template <typename T> int launch_outer_reduce4(const OuterJobs& j, int M, int C,
     LSAM_REQUIRE(R >= 1 && R <= 16 && C % 4 == 0, LSAM_ERR_BAD_ARG, "outer_reduce4: need 1<=R<=16, C%%4==0");
     const int nch = cdiv(M, OR_MCH);
     const size_t job_stride = (size_t)nch * C * 16;
+    ProfScope ps(s, 4.0 * M * (C + 16) * sizeof(T), PROF_OUTER, M, C, R);
     hipLaunchKernelGGL(outer_partial4_kernel<T>, dim3(cdiv(C, 256), nch, 4), dim3(64), 0, s, j, M, C,
                        static_cast<float*>(partial), job_stride);
     LSAM_LAUNCH_CHECK();

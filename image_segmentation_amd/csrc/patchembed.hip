@@ -201,6 +201,7 @@ int launch_patch_embed(const float* frames, const void* wimg, const float* bias,
                  "patch_embed: bad shape");
     LSAM_REQUIRE(aligned16(wimg) && aligned16(bias) && aligned16(pos) && aligned16(out) &&
                      (reinterpret_cast<uintptr_t>(frames) & 3) == 0, LSAM_ERR_BAD_ARG, "patch_embed: alignment");
+    ProfScope ps(s, (double)N * (3.0 * S * S * 4 + (double)(S / 4) * (S / 4) * e0 * 4), PROF_PATCH_EMBED, N, S, e0);
     if (e0 <= 112) return launch_pe<7>(frames, wimg, bias, pos, out, N, S, e0, s);
     return launch_pe<9>(frames, wimg, bias, pos, out, N, S, e0, s);
 }

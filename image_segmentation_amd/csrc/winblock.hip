@@ -404,6 +404,7 @@ int launch_winblock_attn(const WinBlockArgs& a, int nh, hipStream_t s) {
                  "winblock: heads %d x %d", nh, a.hd);
     LSAM_REQUIRE(aligned16(a.x) && aligned16(a.y) && aligned16(a.img) && aligned16(a.gamma) && aligned16(a.beta) &&
                      aligned16(a.bias_p), LSAM_ERR_BAD_ARG, "winblock: pointers must be 16-byte aligned");
+    ProfScope ps(s, (double)a.N * a.H * a.W * nh * a.hd * 8.0, PROF_WINBLOCK, a.N * a.H * a.W, nh * a.hd, 0);   // x in + y out, fp32
     return nh == 1 ? launch_wb<1>(a, s) : launch_wb<2>(a, s);
 }
 

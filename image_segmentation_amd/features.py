@@ -27,6 +27,14 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 @torch.no_grad()
+def extract_batch(trunk, frames: torch.Tensor, pool: Optional[Callable] = None) -> torch.Tensor:
+    """One batch of the pass: frames [n,3,S,S] -> fp32 [n, C] = spatial mean of Hiera.get_embedding's last stage."""
+    pool = ops.spatial_mean if pool is None else pool
+    last = trunk.get_embedding(frames)[-1]                              # NCHW view of NHWC storage
+    return pool(last.permute(0, 2, 3, 1).contiguous())                  # (already contiguous: no copy)
+
+
+@torch.no_grad()
 def extract_features(trunk, frame_source: Callable[[int, int], torch.Tensor], n_frames: int, batch: int,
                      rank: int = 0, world: int = 1, pool: Optional[Callable] = None) -> Tuple[torch.Tensor, int]:
     """Pooled last-stage embedding of frames [lo, hi) = shard_range(n_frames, rank, world).
@@ -35,13 +43,11 @@ def extract_features(trunk, frame_source: Callable[[int, int], torch.Tensor], n_
     (features fp32 [hi-lo, C], lo).  `pool` defaults to the HIP kernel ops.spatial_mean."""
     if batch <= 0:
         raise ValueError("extract_features: batch must be positive")
-    pool = ops.spatial_mean if pool is None else pool
     lo, hi = shard_range(n_frames, rank, world)
     rows = []
     for first in range(lo, hi, batch):
         n = min(batch, hi - first)
-        last = trunk.get_embedding(frame_source(first, n))[-1]          # NCHW view of NHWC storage
-        rows.append(pool(last.permute(0, 2, 3, 1).contiguous()))
+        rows.append(extract_batch(trunk, frame_source(first, n), pool))
     if not rows:
         c = trunk.channel_list[0]
         dev = next(trunk.parameters()).device

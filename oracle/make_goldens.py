@@ -37,6 +37,11 @@ BPLUS = dict(embed_dim=112, num_heads=2)  # sam2_model.py:12
 # Hiera-L (configs/sam2.1/sam2.1_hiera_l.yaml:11-16): head_dim 72, window_spec (8,4,16,8), r = 8
 LARGE = dict(embed_dim=144, num_heads=2, stages=(2, 6, 36, 4), global_att_blocks=(23, 33, 43), window_spec=(8, 4, 16, 8))
 TINY_L = dict(embed_dim=72, num_heads=1, stages=(2, 2, 3, 3), global_att_blocks=(5,), window_spec=(8, 4, 16, 8))
+# miniature of the reference's SECOND factory model (build_small_model, sam2_model.py:92-99: stages [1,2,11,2]): a
+# two-block last stage, so wrap_image_encoder_lora's blocks[-2:] (lora_qkv.py:162) holds the stage-4 ENTRY block --
+# dim != dim_out, q-pool, lagging window 14 -- whose LoRA_qkv touches only the first / last `dim` columns of a
+# 3*dim_out-wide qkv (lora_qkv.py:99,106-107)
+TINY_S = dict(embed_dim=56, num_heads=1, stages=(1, 2, 3, 2), global_att_blocks=(4,))
 
 
 def import_reference():
@@ -140,6 +145,23 @@ def run(R, hiera_kwargs, rank, seed, n, size, tag, full):
     print(f"wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB, loss {loss.item():.6f}")
 
 
+def features(R, hiera_kwargs, rank, seed, n, size, tag):
+    """Hiera.get_embedding (hieradet.py:284-302, the repo-added all-no_grad pass) and the per-frame spatial mean of
+    every stage output: the quantity BASELINE.json configs[4] (train_cl_kmean-style extraction) produces."""
+    torch.manual_seed(0)
+    enc = build_reference_encoder(R, hiera_kwargs, rank, seed)
+    img = synth_frames(n, size, seed)
+    outs = enc.trunk.get_embedding(img)
+    assert not any(o.requires_grad for o in outs)
+    g = {}
+    for i, o in enumerate(outs):                       # NCHW
+        g[f"stage{i}.mean"] = o.double().mean(dim=(2, 3)).float().numpy().copy()
+        g[f"stage{i}.stats"] = stats(o)
+    path = os.path.join(GOLD, tag + ".npz")
+    np.savez_compressed(path, **g)
+    print(f"wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB")
+
+
 def micro_lora_slice(R):
     """LoRA slice rule with dim != dim_out (lora_qkv.py:99,106-107): the adds go
     to the first/last in_features columns, which are NOT the q and v thirds."""
@@ -201,6 +223,10 @@ def main():
         run(R, BPLUS, rank=4, seed=0, n=1, size=1024, tag="bplus_r4_1024", full=False)
     if want("tinyL_r8"):
         run(R, TINY_L, rank=8, seed=0, n=2, size=256, tag="tinyL_r8", full=True)
+    if want("tinyS_r4"):
+        run(R, TINY_S, rank=4, seed=0, n=2, size=256, tag="tinyS_r4", full=True)
+    if want("features_bplus_r4"):
+        features(R, BPLUS, rank=4, seed=0, n=2, size=1024, tag="features_bplus_r4")
     if want("large_r8_1024"):
         run(R, LARGE, rank=8, seed=0, n=1, size=1024, tag="large_r8_1024", full=False)
 

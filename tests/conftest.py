@@ -16,6 +16,8 @@ BPLUS = dict(embed_dim=112, num_heads=2)
 # Hiera-L (configs/sam2.1/sam2.1_hiera_l.yaml:11-16: head_dim 72, window_spec (8,4,16,8)) and a 10-block miniature of it
 LARGE = dict(embed_dim=144, num_heads=2, stages=(2, 6, 36, 4), global_att_blocks=(23, 33, 43), window_spec=(8, 4, 16, 8))
 TINY_L = dict(embed_dim=72, num_heads=1, stages=(2, 2, 3, 3), global_att_blocks=(5,), window_spec=(8, 4, 16, 8))
+# miniature of the reference's small model (sam2_model.py:92-99, stages [1,2,11,2]): blocks[-2:] holds the stage-4 entry block
+TINY_S = dict(embed_dim=56, num_heads=1, stages=(1, 2, 3, 2), global_att_blocks=(4,))
 
 
 def pytest_configure(config):

@@ -3,7 +3,7 @@ no_grad, LoRA applied; hieradet.py:284-302) + the spatial-mean kernel against th
 import pytest
 import torch
 
-from conftest import TINY, rel_err
+from conftest import BPLUS, TINY, load_golden, rel_err
 from test_trunk_gpu import make_encoder
 
 pytestmark = pytest.mark.gpu
@@ -43,3 +43,27 @@ def test_pooled_features_vs_oracle_sharded(dtype, tol):
         ref = O.trunk_forward(tp, frames, spec, n_grad_blocks=0)[-1].mean(dim=(2, 3))   # NCHW stage-4 map -> [N, C]
     assert feats.shape == ref.shape
     assert rel_err(feats, ref) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
+def test_feature_pass_bplus_1024_vs_reference_golden(dtype, tol):
+    """BASELINE.json configs[4] at its own geometry: Hiera-B+ + LoRA r=4 @1024^2, get_embedding + spatial mean of the
+    stage-4 map (896-d per frame), two frames in two shards, against the reference's own get_embedding outputs."""
+    from image_segmentation_amd import ops
+    from image_segmentation_amd.features import extract_features
+    from image_segmentation_amd.synth import synth_frames
+    g = load_golden("features_bplus_r4")
+    enc = make_encoder(BPLUS)
+    enc.trunk.compute_dtype = dtype
+    frames = synth_frames(2, 1024, 0)
+    src = lambda first, n: frames[first:first + n].cuda()
+    parts = [extract_features(enc.trunk, src, 2, 1, rank=r, world=2) for r in range(2)]
+    feats = torch.cat([f for f, _ in parts], 0)
+    assert feats.shape == (2, 896)
+    assert rel_err(feats, g["stage3.mean"]) < tol
+    # the other three stage maps of the same pass
+    with torch.no_grad():
+        stages = enc.trunk.get_embedding(frames.cuda())
+    for i, st in enumerate(stages[:-1]):
+        m = ops.spatial_mean(st.permute(0, 2, 3, 1).contiguous())
+        assert rel_err(m, g[f"stage{i}.mean"]) < tol, i

@@ -86,12 +86,29 @@ def test_tiny_bf16():
         assert rel_err(gr, g["grad." + name]) < 6e-2, name   # bf16 grads: reported, no north-star bound
 
 
+def _check_level_and_stage_stats(enc, out, g, tol, size=1024):
+    """Norm / mean / std of every FPN level and of the four stage-end block outputs against the statistics the reference
+    run recorded (golden `fpn{i}.stats`, `block{stage_end}.stats` = mean, std, L2 norm)."""
+    from image_segmentation_amd.synth import synth_frames
+    for i, f in enumerate(out["backbone_fpn"]):
+        s = g[f"fpn{i}.stats"]
+        f = f.detach().double()
+        assert abs(f.norm().item() - s[2]) < tol * s[2], (i, f.norm().item(), s[2])
+        assert abs(f.std().item() - s[1]) < tol * s[1] + 1e-7, i
+    with torch.no_grad():
+        stages = enc.trunk.get_embedding(synth_frames(1, size, 0, device="cuda"))
+    for st, be in zip(stages, enc.trunk.stage_ends):
+        s = g[f"block{be}.stats"]
+        st = st.double()
+        assert abs(st.norm().item() - s[2]) < tol * s[2], (be, st.norm().item(), s[2])
+        assert abs(st.mean().item() - s[0]) < tol * abs(s[0]) + tol * s[1], be
+
+
 def test_bplus_1024_fp32_vs_reference_golden():
     g = load_golden("bplus_r4_1024")
     enc, out, loss, grads = run(BPLUS, 1, 1024, torch.float32)
     assert rel_err(out["backbone_fpn"][2][:, ::8, ::4, ::4], g["fpn2.sub"]) < 1e-4
-    s = g["fpn2.stats"]
-    assert abs(out["backbone_fpn"][2].double().norm().item() - s[2]) < 1e-4 * s[2]
+    _check_level_and_stage_stats(enc, out, g, 1e-4)
     assert abs(loss.item() - float(g["loss"])) < 1e-4 * float(g["loss"])
     total = 0
     for name, gr in grads.items():
@@ -104,8 +121,16 @@ def test_bplus_1024_bf16_vs_reference_golden():
     g = load_golden("bplus_r4_1024")
     enc, out, loss, grads = run(BPLUS, 1, 1024, torch.bfloat16)
     assert rel_err(out["backbone_fpn"][2].float()[:, ::8, ::4, ::4], g["fpn2.sub"]) < 2e-2
-    s = g["fpn2.stats"]
-    assert abs(out["backbone_fpn"][2].double().norm().item() - s[2]) < 2e-2 * s[2]
+    _check_level_and_stage_stats(enc, out, g, 2e-2)
+    assert abs(loss.item() - float(g["loss"])) < 2e-2 * float(g["loss"])
+    # bf16 LoRA gradients (what bench.py's step computes): BASELINE.json bounds fp32 gradients only (1e-3); the bf16
+    # ones are reported and held to the bf16 embedding tolerance class (measured on MI355X: see DESIGN.md section 2)
+    worst = 0.0
+    for name, gr in grads.items():
+        e = rel_err(gr, g["grad." + name])
+        worst = max(worst, e)
+        print(f"bf16 grad rel-err {name}: {e:.3e}")
+    assert worst < 3e-2, worst   # measured 6e-3 .. 1.3e-2
 
 
 def test_batch_independence_and_repeatability():
