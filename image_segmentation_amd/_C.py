@@ -84,6 +84,7 @@ def lib() -> C.CDLL:
         L.lsam_attention_fwd.argtypes = [i, vp, i, vp, vp, vp, i, vp, i, i, i, i, i, i, i, vp]
         L.lsam_attention_fwd_pooled_q.argtypes = [i, vp, i, vp, vp, vp, i, vp, i, vp, i, i, i, i, i, i, vp]
         L.lsam_attention_bwd.argtypes = [i, vp, i, vp, vp, i, vp, vp, i, i, i, i, i, i, i, vp]
+        L.lsam_attention_bwd_qpool.argtypes = [i, vp, i, vp, vp, i, vp, vp, i, i, i, i, i, i, i, i, vp]
         L.lsam_maxpool2x2.argtypes = [vp, vp, i, i, i, i, vp]
         L.lsam_spatial_mean.argtypes = [vp, vp, i, i, i, vp]
         L.lsam_cast.argtypes = [i, vp, i, vp, i, i, i, vp]
@@ -148,5 +149,5 @@ EXPORTED = [
     "lsam_mlp_block_fwd", "lsam_tail_block_image_bytes", "lsam_tail_block_vec_floats", "lsam_tail_block_pack",
     "lsam_tail_block_fwd", "lsam_patch_embed_image_bytes", "lsam_patch_embed_pack", "lsam_patch_embed_fwd", "lsam_linear_maxpool2x2",
     "lsam_lateral_conv_image_bytes", "lsam_lateral_conv_pack", "lsam_lateral_conv_fwd", "lsam_mlp_block_fwd_next_norm", "lsam_attention_fwd_pooled_q",
-    "lsam_outer_reduce_static_max_ws", "lsam_outer_reduce_static_init", "lsam_outer_reduce_static",
+    "lsam_attention_bwd_qpool", "lsam_outer_reduce_static_max_ws", "lsam_outer_reduce_static_init", "lsam_outer_reduce_static",
 ]

@@ -917,168 +917,241 @@ template int launch_attn_fwd<float>(const AttnArgs&, hipStream_t);
 template int launch_attn_fwd<bf16>(const AttnArgs&, hipStream_t);
 
 // ---------------------------------------------------------------------------------------------
-// Backward for the LoRA blocks (un-pooled windows with <= 64 keys).  One workgroup per
-// (window, head); everything lives in LDS in fp32:
-//   P = exp(S*scale - lse), dP = dO V^T, delta_i = sum_j P_ij dP_ij (= rowsum(dO*O)),
-//   dS = P (dP - delta) scale, dQ = dS K, dK = dS^T Q, dV = P^T dO.
-// Every real token belongs to exactly one window, so each dq/dk/dv element is written once.
+// General backward for the LoRA blocks: windows with at most 64 queries and ANY number of keys (streamed in tiles
+// of 64), head_dim <= 96, optional 2x2 q-pool (the stage-entry block a two-block last stage puts under
+// lora_qkv.py:162's blocks[-2:]: 49 pooled queries against 196 keys).  One workgroup per (window, head), fp32 in LDS:
+//   P = exp(S*scale - lse), dP = dO V^T, delta_i = sum_j P_ij dP_ij, dS = P (dP - delta) scale,
+//   dQ = dS K, dK = dS^T Q, dV = P^T dO.
+// Pass A streams the key tiles once for delta, pass B again for dS and the three products (dQ stays in registers
+// across tiles).  Pooled queries: q_i = max over the 2x2 input tokens per channel (do_pool, hieradet.py:25-36,69-71);
+// dq_i[c] goes to the FIRST maximal token (MaxPool2d's backward) and the other three get 0, so every q, k, v element
+// of a real token is written exactly once and dqkv needs no clearing.  Pad-token keys are constants: no gradient.
 // ---------------------------------------------------------------------------------------------
-constexpr int BW_NK = 64;
+constexpr int BW_T = 64;          // queries per window (max) and keys per tile
+constexpr int BW_MAX_HD = 96;
+constexpr int BW_NB = BW_MAX_HD / 16;
+static size_t attn_bwd_gen_lds(int hd) {
+    return (size_t)(4 * BW_T * (hd + 1) + 2 * BW_T * (BW_T + 1) + 2 * BW_T) * sizeof(float) + 6 * BW_T * sizeof(int) +
+           (size_t)BW_T * hd;
+}
 
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdArgs p, const float scale) {
+__global__ __launch_bounds__(256) void attn_bwd_gen_kernel(const AttnBwdArgs p, const float scale) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int hd = p.hd, LDH = hd + 1, LDP = BW_NK + 1;
+    const int hd = p.hd, LDH = hd + 1, LDP = BW_T + 1;
     float* Qs = sm;
-    float* Ks = Qs + BW_NK * LDH;
-    float* Vs = Ks + BW_NK * LDH;
-    float* Ds = Vs + BW_NK * LDH;   // dO
-    float* Ps = Ds + BW_NK * LDH;
-    float* Ss = Ps + BW_NK * LDP;   // dP, then dS
-    float* lse_s = Ss + BW_NK * LDP;
-    float* del_s = lse_s + BW_NK;
-    int* qtok_s = reinterpret_cast<int*>(del_s + BW_NK);
-    int* ktok_s = qtok_s + BW_NK;
+    float* Ks = Qs + BW_T * LDH;
+    float* Vs = Ks + BW_T * LDH;
+    float* Ds = Vs + BW_T * LDH;   // dO
+    float* Ps = Ds + BW_T * LDH;
+    float* Ss = Ps + BW_T * LDP;   // dP, then dS
+    float* lse_s = Ss + BW_T * LDP;
+    float* del_s = lse_s + BW_T;
+    int* otok_s = reinterpret_cast<int*>(del_s + BW_T);   // output-grid token of a query row (dO, lse), -1 = none
+    int* qsrc_s = otok_s + BW_T;                          // 4 input-grid tokens a (pooled) query is the max of
+    int* ktok_s = qsrc_s + 4 * BW_T;                      // input-grid token of a key of the current tile; -1 pad, -2 none
+    unsigned char* amax_s = reinterpret_cast<unsigned char*>(ktok_s + BW_T);   // [query][d]: which of the 4 tokens
 
     const int tid = threadIdx.x;
-    const int H = p.H, W = p.W, nh = p.nh, dout = nh * hd, ws = p.ws;
+    const int H = p.H, W = p.W, nh = p.nh, dout = nh * hd, ws = p.ws, pool = p.pool;
     const int nwy = (H + ws - 1) / ws, nwx = (W + ws - 1) / ws;
     const int h = blockIdx.y;
     const int win = blockIdx.x % (nwy * nwx), n = blockIdx.x / (nwy * nwx);
     const int wy = win / nwx, wx = win % nwx;
-    const int rh = min(ws, H - wy * ws), rw = min(ws, W - wx * ws);
-    const int nq = rh * rw, nk = ws * ws;
+    const int qs = ws / pool, Ho = H / pool, Wo = W / pool;
+    const int rh = min(qs, Ho - wy * qs), rw = min(qs, Wo - wx * qs);
+    const int nq = rh > 0 && rw > 0 ? rh * rw : 0;
+    const int nk = ws * ws;
+    if (nq == 0) return;   // a window of pad tokens only (uniform for the workgroup)
     const T* __restrict__ qkv = static_cast<const T*>(p.qkv);
     const T* __restrict__ dO = static_cast<const T*>(p.dout);
-    const size_t img_tok = (size_t)n * H * W;
+    const size_t img_in = (size_t)n * H * W, img_out = (size_t)n * Ho * Wo;
 
-    if (tid < BW_NK) {
-        int qt = -1, kt = -1;
-        if (tid < nq) qt = (int)(img_tok + (size_t)(wy * ws + tid / rw) * W + (wx * ws + tid % rw));
-        if (tid < nk) {
-            const int y = wy * ws + tid / ws, x = wx * ws + tid % ws;
-            if (y < H && x < W) kt = (int)(img_tok + (size_t)y * W + x);
+    if (tid < BW_T) {
+        int ot = -1;
+        int src[4] = {-1, -1, -1, -1};
+        if (tid < nq) {
+            const int py = tid / rw, px = tid % rw;
+            ot = (int)(img_out + (size_t)(wy * qs + py) * Wo + (wx * qs + px));
+            const int y0 = wy * ws + pool * py, x0 = wx * ws + pool * px;
+            src[0] = (int)(img_in + (size_t)y0 * W + x0);
+            if (pool == 2) {
+                src[1] = src[0] + 1;
+                src[2] = src[0] + W;
+                src[3] = src[0] + W + 1;
+            }
         }
-        qtok_s[tid] = qt;
-        ktok_s[tid] = kt;
-        lse_s[tid] = qt >= 0 ? p.lse[(size_t)qt * nh + h] : 0.f;
+        otok_s[tid] = ot;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) qsrc_s[4 * tid + k] = src[k];
+        lse_s[tid] = ot >= 0 ? p.lse[(size_t)ot * nh + h] : 0.f;
+        del_s[tid] = 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < BW_NK * hd; i += 256) {
+    for (int i = tid; i < BW_T * hd; i += 256) {
         const int r = i / hd, d = i % hd;
-        const int qt = qtok_s[r], kt = ktok_s[r];
-        float q = 0.f, dv = 0.f, k = 0.f, v = 0.f;
-        if (qt >= 0) {
-            q = to_f(qkv[(size_t)qt * p.ldqkv + h * hd + d]);
-            dv = to_f(dO[(size_t)qt * p.lddo + h * hd + d]);
-        }
-        if (r < nk) {
-            if (kt >= 0) {
-                k = to_f(qkv[(size_t)kt * p.ldqkv + dout + h * hd + d]);
-                v = to_f(qkv[(size_t)kt * p.ldqkv + 2 * dout + h * hd + d]);
-            } else {
-                k = to_f(from_f<T>(p.bias[dout + h * hd + d]));
-                v = to_f(from_f<T>(p.bias[2 * dout + h * hd + d]));
+        const int ot = otok_s[r];
+        float q = 0.f, dv = 0.f;
+        int am = 0;
+        if (ot >= 0) {
+            q = to_f(qkv[(size_t)qsrc_s[4 * r] * p.ldqkv + h * hd + d]);
+            if (pool == 2) {
+#pragma unroll
+                for (int k = 1; k < 4; ++k) {
+                    const float v = to_f(qkv[(size_t)qsrc_s[4 * r + k] * p.ldqkv + h * hd + d]);
+                    if (v > q) { q = v; am = k; }   // strict: the first maximum keeps the gradient
+                }
             }
+            dv = to_f(dO[(size_t)ot * p.lddo + h * hd + d]);
         }
         Qs[r * LDH + d] = q;
         Ds[r * LDH + d] = dv;
-        Ks[r * LDH + d] = k;
-        Vs[r * LDH + d] = v;
+        amax_s[r * hd + d] = (unsigned char)am;
     }
-    __syncthreads();
 
     const int ti = tid >> 4, tj = tid & 15;
-    {
-        float s[4][4], dp[4][4];
+    const int nkt = (nk + BW_T - 1) / BW_T;
+    float dq[4][BW_NB];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) s[a][b] = dp[a][b] = 0.f;
-        for (int d = 0; d < hd; ++d) {
-            float qa[4], da[4], kb[4], vb[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                qa[a] = Qs[(ti + 16 * a) * LDH + d];
-                da[a] = Ds[(ti + 16 * a) * LDH + d];
-                kb[a] = Ks[(tj + 16 * a) * LDH + d];
-                vb[a] = Vs[(tj + 16 * a) * LDH + d];
+        for (int b = 0; b < BW_NB; ++b) dq[a][b] = 0.f;
+
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll 1
+        for (int kt = 0; kt < nkt; ++kt) {
+            __syncthreads();   // previous tile fully consumed (and Q / dO / del_s visible on the first trip)
+            if (tid < BW_T) {
+                const int j = kt * BW_T + tid;
+                int tk = -2;
+                if (j < nk) {
+                    const int y = wy * ws + j / ws, x = wx * ws + j % ws;
+                    tk = (y < H && x < W) ? (int)(img_in + (size_t)y * W + x) : -1;
+                }
+                ktok_s[tid] = tk;
             }
+            __syncthreads();
+            for (int i = tid; i < BW_T * hd; i += 256) {
+                const int r = i / hd, d = i % hd;
+                const int tk = ktok_s[r];
+                float k = 0.f, v = 0.f;
+                if (tk >= 0) {
+                    k = to_f(qkv[(size_t)tk * p.ldqkv + dout + h * hd + d]);
+                    v = to_f(qkv[(size_t)tk * p.ldqkv + 2 * dout + h * hd + d]);
+                } else if (tk == -1) {
+                    k = to_f(from_f<T>(p.bias[dout + h * hd + d]));
+                    v = to_f(from_f<T>(p.bias[2 * dout + h * hd + d]));
+                }
+                Ks[r * LDH + d] = k;
+                Vs[r * LDH + d] = v;
+            }
+            __syncthreads();
+            {
+                float s[4][4], dp[4][4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) s[a][b] = dp[a][b] = 0.f;
+                for (int d = 0; d < hd; ++d) {
+                    float qa[4], da[4], kb[4], vb[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        qa[a] = Qs[(ti + 16 * a) * LDH + d];
+                        da[a] = Ds[(ti + 16 * a) * LDH + d];
+                        kb[a] = Ks[(tj + 16 * a) * LDH + d];
+                        vb[a] = Vs[(tj + 16 * a) * LDH + d];
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            s[a][b] += qa[a] * kb[b];
+                            dp[a][b] += da[a] * vb[b];
+                        }
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int i = ti + 16 * a, j = tj + 16 * b;
+                        const bool ok = i < nq && kt * BW_T + j < nk;
+                        const float pe = ok ? __expf(s[a][b] * scale - lse_s[i]) : 0.f;
+                        Ps[i * LDP + j] = pe;
+                        Ss[i * LDP + j] = pass == 0 ? pe * dp[a][b] : pe * (dp[a][b] - del_s[i]) * scale;
+                    }
+            }
+            __syncthreads();
+            if (pass == 0) {
+                if (tid < BW_T) {
+                    float dl = 0.f;
+                    for (int j = 0; j < BW_T; ++j) dl += Ss[tid * LDP + j];
+                    del_s[tid] += dl;
+                }
+                continue;
+            }
+            // dQ += dS K (rows ti+16a, channels tj+16b);  dK = dS^T Q,  dV = P^T dO  (key rows ti+16a of this tile)
+            float dk[4][BW_NB], dvv[4][BW_NB];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    s[a][b] += qa[a] * kb[b];
-                    dp[a][b] += da[a] * vb[b];
+                for (int b = 0; b < BW_NB; ++b) dk[a][b] = dvv[a][b] = 0.f;
+            for (int j = 0; j < BW_T; ++j) {
+                float ds_r[4], ds_c[4], p_c[4], kd[BW_NB], qd[BW_NB], dd[BW_NB];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    ds_r[a] = Ss[(ti + 16 * a) * LDP + j];   // dS[i][j]   (dQ: sum over keys j)
+                    ds_c[a] = Ss[j * LDP + (ti + 16 * a)];   // dS[j][i']  (dK: sum over queries j)
+                    p_c[a] = Ps[j * LDP + (ti + 16 * a)];    // P[j][i']   (dV)
                 }
-        }
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < BW_NB; ++b) {
+                    const int d = tj + 16 * b;
+                    const bool d_ok = d < hd;
+                    kd[b] = d_ok ? Ks[j * LDH + d] : 0.f;
+                    qd[b] = d_ok ? Qs[j * LDH + d] : 0.f;
+                    dd[b] = d_ok ? Ds[j * LDH + d] : 0.f;
+                }
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int i = ti + 16 * a, j = tj + 16 * b;
-                const bool ok = i < nq && j < nk;
-                Ps[i * LDP + j] = ok ? __expf(s[a][b] * scale - lse_s[i]) : 0.f;
-                Ss[i * LDP + j] = ok ? dp[a][b] : 0.f;
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < BW_NB; ++b) {
+                        dq[a][b] += ds_r[a] * kd[b];
+                        dk[a][b] += ds_c[a] * qd[b];
+                        dvv[a][b] += p_c[a] * dd[b];
+                    }
             }
-    }
-    __syncthreads();
-    if (tid < BW_NK) {
-        float dl = 0.f;
-        for (int j = 0; j < BW_NK; ++j) dl += Ps[tid * LDP + j] * Ss[tid * LDP + j];
-        del_s[tid] = dl;
-    }
-    __syncthreads();
+            T* __restrict__ dqkv = static_cast<T*>(p.dqkv);
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < 4; ++a) {
+                const int tk = ktok_s[ti + 16 * a];
+                if (tk < 0) continue;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int i = ti + 16 * a, j = tj + 16 * b;
-            Ss[i * LDP + j] = Ps[i * LDP + j] * (Ss[i * LDP + j] - del_s[i]) * scale;
-        }
-    __syncthreads();
-
-    // outputs: rows ti+16a, columns tj+16b (< hd)
-    float dq[4][4], dk[4][4], dvv[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) dq[a][b] = dk[a][b] = dvv[a][b] = 0.f;
-    for (int j = 0; j < BW_NK; ++j) {
-        float ds_r[4], ds_c[4], p_c[4], kd[4], qd[4], dd[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            ds_r[a] = Ss[(ti + 16 * a) * LDP + j];   // dS[i][j]   (dQ: sum over keys j)
-            ds_c[a] = Ss[j * LDP + (ti + 16 * a)];   // dS[j][i']  (dK: sum over queries j)
-            p_c[a] = Ps[j * LDP + (ti + 16 * a)];    // P[j][i']   (dV)
-            const int d = tj + 16 * a;
-            const bool dv_ok = d < hd;
-            kd[a] = dv_ok ? Ks[j * LDH + d] : 0.f;
-            qd[a] = dv_ok ? Qs[j * LDH + d] : 0.f;
-            dd[a] = dv_ok ? Ds[j * LDH + d] : 0.f;
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                dq[a][b] += ds_r[a] * kd[b];
-                dk[a][b] += ds_c[a] * qd[b];
-                dvv[a][b] += p_c[a] * dd[b];
+                for (int b = 0; b < BW_NB; ++b) {
+                    const int d = tj + 16 * b;
+                    if (d >= hd) continue;
+                    dqkv[(size_t)tk * p.lddqkv + dout + h * hd + d] = from_f<T>(dk[a][b]);
+                    dqkv[(size_t)tk * p.lddqkv + 2 * dout + h * hd + d] = from_f<T>(dvv[a][b]);
+                }
             }
+        }
     }
     T* __restrict__ dqkv = static_cast<T*>(p.dqkv);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const int r = ti + 16 * a;
-        const int qt = qtok_s[r], kt = ktok_s[r];
+        if (otok_s[r] < 0) continue;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int b = 0; b < BW_NB; ++b) {
             const int d = tj + 16 * b;
             if (d >= hd) continue;
-            if (qt >= 0) dqkv[(size_t)qt * p.lddqkv + h * hd + d] = from_f<T>(dq[a][b]);
-            if (kt >= 0) {
-                dqkv[(size_t)kt * p.lddqkv + dout + h * hd + d] = from_f<T>(dk[a][b]);
-                dqkv[(size_t)kt * p.lddqkv + 2 * dout + h * hd + d] = from_f<T>(dvv[a][b]);
+            if (pool == 1) {
+                dqkv[(size_t)qsrc_s[4 * r] * p.lddqkv + h * hd + d] = from_f<T>(dq[a][b]);
+            } else {
+                const int am = amax_s[r * hd + d];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    dqkv[(size_t)qsrc_s[4 * r + k] * p.lddqkv + h * hd + d] = from_f<T>(k == am ? dq[a][b] : 0.f);
             }
         }
     }
@@ -1294,17 +1367,21 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const AttnBwdArgs p,
 template <typename T> int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t s) {
     LSAM_REQUIRE(a.qkv && a.bias && a.dout && a.lse && a.dqkv, LSAM_ERR_BAD_ARG, "attention_bwd: null pointer");
     LSAM_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.nh > 0, LSAM_ERR_BAD_ARG, "attention_bwd: empty shape");
-    LSAM_REQUIRE(a.ws > 0 && a.ws * a.ws <= BW_NK, LSAM_ERR_UNSUPPORTED,
-                 "attention_bwd: window %d not supported (need 0 < ws*ws <= %d)", a.ws, BW_NK);
-    LSAM_REQUIRE(a.hd > 0 && a.hd <= 64, LSAM_ERR_UNSUPPORTED,
-                 "attention_bwd: head_dim %d > 64 (Hiera-L) has a forward path only", a.hd);
+    LSAM_REQUIRE(a.pool == 1 || a.pool == 2, LSAM_ERR_UNSUPPORTED, "attention_bwd: q-pool stride %d", a.pool);
+    LSAM_REQUIRE(a.ws > 0 && (a.ws / a.pool) * (a.ws / a.pool) <= BW_T, LSAM_ERR_UNSUPPORTED,
+                 "attention_bwd: window %d (q-pool %d) has more than %d queries, or is global: not supported", a.ws, a.pool, BW_T);
+    LSAM_REQUIRE(a.pool == 1 || (a.ws % 2 == 0 && a.H % 2 == 0 && a.W % 2 == 0), LSAM_ERR_UNSUPPORTED,
+                 "attention_bwd: pooled blocks need an even window and grid (ws=%d)", a.ws);
+    LSAM_REQUIRE(a.hd > 0 && a.hd <= BW_MAX_HD, LSAM_ERR_UNSUPPORTED, "attention_bwd: head_dim %d > %d", a.hd, BW_MAX_HD);
     LSAM_REQUIRE(a.ldqkv >= 3 * a.nh * a.hd && a.lddqkv >= 3 * a.nh * a.hd && a.lddo >= a.nh * a.hd,
                  LSAM_ERR_BAD_ARG, "attention_bwd: leading dimensions");
     const int nwy = cdiv(a.H, a.ws), nwx = cdiv(a.W, a.ws);
+    ProfScope ps(s, 10.0 * a.N * (a.H / a.pool) * (a.W / a.pool) * (double)(a.ws * a.ws) * a.nh * a.hd, PROF_ATTN_BWD,
+                 a.N * (a.H / a.pool) * (a.W / a.pool), a.ws * a.ws, a.nh * a.hd);   // 2.5 x the forward's 4 nq nk hd
     if constexpr (sizeof(T) == 2) {
         const bool al16 = ((reinterpret_cast<uintptr_t>(a.qkv) | reinterpret_cast<uintptr_t>(a.dout)) & 15) == 0;
-        if (a.hd % 8 == 0 && a.ldqkv % 8 == 0 && a.lddo % 8 == 0 && a.lddqkv % 4 == 0 && al16 &&
-            (reinterpret_cast<uintptr_t>(a.dqkv) & 7) == 0) {
+        if (a.pool == 1 && a.ws * a.ws <= 64 && a.hd <= 64 && a.hd % 8 == 0 && a.ldqkv % 8 == 0 && a.lddo % 8 == 0 &&
+            a.lddqkv % 4 == 0 && al16 && (reinterpret_cast<uintptr_t>(a.dqkv) & 7) == 0) {
             constexpr int LDSB = 4 * (4 * 64 * 128 + 512);
             static thread_local bool attr_set = false;
             if (!attr_set) {
@@ -1319,11 +1396,10 @@ template <typename T> int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t s) {
             return LSAM_OK;
         }
     }
-    const int LDH = a.hd + 1, LDP = BW_NK + 1;
-    const size_t lds = (size_t)(4 * BW_NK * LDH + 2 * BW_NK * LDP + 2 * BW_NK) * sizeof(float) + 2 * BW_NK * sizeof(int);
-    auto kern = attn_bwd_kernel<T>;
+    const size_t lds = attn_bwd_gen_lds(a.hd);
+    auto kern = attn_bwd_gen_kernel<T>;
     LSAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds));
+                                 (int)attn_bwd_gen_lds(BW_MAX_HD)));
     hipLaunchKernelGGL(kern, dim3(a.N * nwy * nwx, a.nh), dim3(256), lds, s, a, 1.0f / sqrtf((float)a.hd));
     LSAM_LAUNCH_CHECK();
     return LSAM_OK;

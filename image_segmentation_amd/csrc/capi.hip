@@ -98,6 +98,15 @@ int lsam_attention_bwd(int dtype, const void* qkv, int ldqkv, const float* bias,
     DISPATCH(dtype, launch_attn_bwd<float>(a, s), launch_attn_bwd<bf16>(a, s));
 }
 
+int lsam_attention_bwd_qpool(int dtype, const void* qkv, int ldqkv, const float* bias, const void* dout, int lddo,
+                             const float* lse, void* dqkv, int lddqkv, int N, int H, int W, int ws, int pool, int nh, int hd,
+                             lsam_stream_t stream) {
+    AttnBwdArgs a{qkv, ldqkv, bias, dout, lddo, lse, dqkv, lddqkv, N, H, W, ws, nh, hd};
+    a.pool = pool;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DISPATCH(dtype, launch_attn_bwd<float>(a, s), launch_attn_bwd<bf16>(a, s));
+}
+
 int lsam_spatial_mean(const float* x, float* out, int N, int HW, int C, lsam_stream_t stream) {
     return launch_spatial_mean(x, out, N, HW, C, static_cast<hipStream_t>(stream));
 }

@@ -101,29 +101,35 @@ static FwdWs plan_ws(const lsam_hiera* h, int N, bool with_grad) {
     w.a = b.take(a);
     w.hbuf = b.take(hb);
     if (with_grad && h->cfg.n_lora_blocks > 0) {
-        const BlockGeom& g = h->blk.back();
-        const size_t M = (size_t)N * g.gin * g.gin, d = g.dim;
+        // per LoRA block: what its backward needs; the first one may be a stage-entry block (dim != dim_out, q-pool)
+        size_t moq = 0, miq = 0, mid = 0, part = 0;
         for (int i = 0; i < h->cfg.n_lora_blocks; ++i) {
+            const BlockGeom& g = h->blk[h->first_lora + i];
+            const size_t Mi = (size_t)N * g.gin * g.gin, Mo = (size_t)N * g.gout * g.gout, d = g.dim, q = g.dout;
             auto& s = w.sv[i];
-            s.st1 = b.take(M * 2 * sizeof(float));
-            s.xn = b.take(M * (d + AUG) * e);
-            s.qkv = b.take(M * 3 * d * e);
-            s.lse = b.take(M * g.heads * sizeof(float));
-            s.y = b.take(M * d * sizeof(float));
-            s.st2 = b.take(M * 2 * sizeof(float));
-            s.pre = b.take(M * 4 * d * e);
-            s.xout = b.take(M * d * sizeof(float));
+            s.st1 = b.take(Mi * 2 * sizeof(float));
+            s.xn = b.take(Mi * (d + AUG) * e);
+            s.qkv = b.take(Mi * 3 * q * e);
+            s.lse = b.take(Mo * g.heads * sizeof(float));
+            s.y = b.take(Mo * q * sizeof(float));
+            s.st2 = b.take(Mo * 2 * sizeof(float));
+            s.pre = b.take(Mo * 4 * q * e);
+            s.xout = b.take(Mo * q * sizeof(float));
+            moq = std::max(moq, Mo * q);
+            miq = std::max(miq, Mi * (3 * q + AUG));
+            mid = std::max(mid, Mi * d);
+            part = std::max(part, outer_reduce_ws((int)Mi, (int)d));
         }
-        w.gT = b.take(M * d * e);
-        w.dh = b.take(M * 4 * d * e);
-        w.dyn = b.take(M * d * sizeof(float));
-        w.dy = b.take(M * d * sizeof(float));
-        w.dyT = b.take(M * d * e);
-        w.da = b.take(M * d * e);
-        w.dqkv = b.take(M * (3 * d + AUG) * e);
-        w.dxn = b.take(M * d * sizeof(float));
-        w.dxprev = b.take(M * d * sizeof(float));
-        w.partial = b.take(4 * outer_reduce_ws((int)M, (int)d));
+        w.gT = b.take(moq * e);
+        w.dh = b.take(moq * 4 * e);
+        w.dyn = b.take(moq * sizeof(float));
+        w.dy = b.take(moq * sizeof(float));
+        w.dyT = b.take(moq * e);
+        w.da = b.take(moq * e);
+        w.dqkv = b.take(miq * e);
+        w.dxn = b.take(mid * sizeof(float));
+        w.dxprev = b.take(mid * sizeof(float));
+        w.partial = b.take(4 * part);
     }
     w.total = b.cur;
     return w;
@@ -134,10 +140,12 @@ static FwdWs plan_ws(const lsam_hiera* h, int N, bool with_grad) {
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void pack_lora_kernel(const float* __restrict__ aq, const float* __restrict__ bq,
-                                 const float* __restrict__ av, const float* __restrict__ bv, int d, int r,
+                                 const float* __restrict__ av, const float* __restrict__ bv, int d, int q, int r,
                                  T* __restrict__ wqkv, T* __restrict__ acat, T* __restrict__ bT,
                                  T* __restrict__ wqkvT) {
-    const int kq = d + AUG, n3 = 3 * d;
+    // d = in_features of the wrapped qkv (LoRA_qkv.d_model, lora_qkv.py:99), q = dim_out: the adds go to the first and
+    // the last d of the 3q output columns (lora_qkv.py:106-107), which are the q and v thirds only when d == q
+    const int kq = d + AUG, n3 = 3 * q;
     const long n_w = (long)n3 * AUG, n_a = (long)AUG * d, n_b = (long)AUG * n3, n_t = wqkvT ? (long)d * AUG : 0;
     const long total = n_w + n_a + n_b + n_t;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -240,7 +248,7 @@ static int pack_lora_t(lsam_hiera* h, const lsam_lora_params_t* lp, void* arena,
         const BlockOff& o = h->off[bi];
         LSAM_REQUIRE(lp[i].a_q && lp[i].b_q && lp[i].a_v && lp[i].b_v, LSAM_ERR_BAD_ARG, "pack_lora: null LoRA factor");
         hipLaunchKernelGGL(pack_lora_kernel<T>, dim3(256), dim3(256), 0, s, lp[i].a_q, lp[i].b_q, lp[i].a_v,
-                           lp[i].b_v, g.dim, r, at<T>(arena, o.wqkv), at<T>(arena, o.acat), at<T>(arena, o.bT),
+                           lp[i].b_v, g.dim, g.dout, r, at<T>(arena, o.wqkv), at<T>(arena, o.acat), at<T>(arena, o.bT),
                            g.need_dx ? at<T>(arena, o.wqkvT) : (T*)nullptr);
         LSAM_LAUNCH_CHECK();
     }
@@ -417,7 +425,11 @@ static int backward_t(lsam_hiera* h, const float* grad_out, int N, float* const*
         const BlockGeom& g = h->blk[bi];
         const BlockOff& o = h->off[bi];
         const auto& sv = w.sv[gi];
-        const int d = g.dim, M = N * g.gin * g.gin, ldq = 3 * d + AUG;
+        // d = block input width (= LoRA width), q = output width; Mi / Mo input / output tokens.  They differ only for a
+        // stage-entry block (dim != dim_out, q-pool), which can only be the FIRST LoRA block: its shortcut
+        // pool(proj(norm1(x))) (hieradet.py:139-140) has no trainable parameter and x carries no gradient, so the
+        // gradient flows through the attention branch alone and stops at the LoRA factors.
+        const int d = g.dim, q = g.dout, M = N * g.gin * g.gin, Mo = N * g.gout * g.gout, ldq = 3 * q + AUG;
         T* gT = at<T>(ws, w.gT);
         T* dh = at<T>(ws, w.dh);
         float* dyn = at<float>(ws, w.dyn);
@@ -427,27 +439,28 @@ static int backward_t(lsam_hiera* h, const float* grad_out, int N, float* const*
         T* dqkv = at<T>(ws, w.dqkv);
         T* xn = at<T>(ws, sv.xn);
         // out = y + fc2(gelu(fc1(norm2(y))))
-        LSAM_TRY(launch_cast<T>(dout, d, gT, d, M, d, s));
-        LSAM_TRY(linear<T>(gT, d, at<T>(arena, o.w2T), d, nullptr, nullptr, 0, 0, at<T>(ws, sv.pre), 4 * d, dh, 4 * d,
-                           nullptr, 0, LSAM_EPI_GELU_BWD, M, 4 * d, d, s));
-        LSAM_TRY(linear<T>(dh, 4 * d, at<T>(arena, o.w1T), 4 * d, nullptr, nullptr, 0, 0, nullptr, 0, dyn, d, nullptr, 0,
-                           LSAM_EPI_OUT_F32, M, d, 4 * d, s));
-        LSAM_TRY(launch_ln_bwd<T>(dyn, d, at<float>(ws, sv.y), d, at<float>(ws, sv.st2), at<float>(arena, o.ln2w), dout,
-                                  d, dy, d, dyT, d, M, d, s));
-        // y = x + proj(attn(qkv))
-        LSAM_TRY(linear<T>(dyT, d, at<T>(arena, o.wprojT), d, nullptr, nullptr, 0, 0, nullptr, 0, da, d, nullptr, 0, 0, M,
-                           d, d, s));
-        AttnBwdArgs ab{at<T>(ws, sv.qkv), 3 * d, at<float>(arena, o.bqkv), da, d, at<float>(ws, sv.lse), dqkv, ldq,
-                       N, g.gin, g.gin, g.ws, g.heads, d / g.heads};
+        LSAM_TRY(launch_cast<T>(dout, q, gT, q, Mo, q, s));
+        LSAM_TRY(linear<T>(gT, q, at<T>(arena, o.w2T), q, nullptr, nullptr, 0, 0, at<T>(ws, sv.pre), 4 * q, dh, 4 * q,
+                           nullptr, 0, LSAM_EPI_GELU_BWD, Mo, 4 * q, q, s));
+        LSAM_TRY(linear<T>(dh, 4 * q, at<T>(arena, o.w1T), 4 * q, nullptr, nullptr, 0, 0, nullptr, 0, dyn, q, nullptr, 0,
+                           LSAM_EPI_OUT_F32, Mo, q, 4 * q, s));
+        LSAM_TRY(launch_ln_bwd<T>(dyn, q, at<float>(ws, sv.y), q, at<float>(ws, sv.st2), at<float>(arena, o.ln2w), dout,
+                                  q, dy, q, dyT, q, Mo, q, s));
+        // y = shortcut + proj(attn(qkv))
+        LSAM_TRY(linear<T>(dyT, q, at<T>(arena, o.wprojT), q, nullptr, nullptr, 0, 0, nullptr, 0, da, q, nullptr, 0, 0, Mo,
+                           q, q, s));
+        AttnBwdArgs ab{at<T>(ws, sv.qkv), 3 * q, at<float>(arena, o.bqkv), da, q, at<float>(ws, sv.lse), dqkv, ldq,
+                       N, g.gin, g.gin, g.ws, g.heads, q / g.heads};
+        ab.pool = g.pool;
         LSAM_TRY(launch_attn_bwd<T>(ab, s));
-        // t = [dq.B_q | dv.B_v] into the 32 augmented columns of dqkv
-        LSAM_TRY(linear<T>(dqkv, ldq, at<T>(arena, o.bT), 3 * d, nullptr, nullptr, 0, 0, nullptr, 0, dqkv + 3 * d, ldq,
-                           nullptr, 0, 0, M, AUG, 3 * d, s));
-        // LoRA gradients (token reductions): dB = dq^T u, dA = t^T xn
+        // t = [dq[:, :d].B_q | dv[:, -d:].B_v] into the 32 augmented columns of dqkv
+        LSAM_TRY(linear<T>(dqkv, ldq, at<T>(arena, o.bT), 3 * q, nullptr, nullptr, 0, 0, nullptr, 0, dqkv + 3 * q, ldq,
+                           nullptr, 0, 0, M, AUG, 3 * q, s));
+        // LoRA gradients (token reductions): dB = dqkv[:, first / last d]^T u, dA = t^T xn
         void* part = at<char>(ws, w.partial);
         float* const* G = lora_grads + 4 * gi;
-        const OuterJobs oj{{xn, dqkv, xn, dqkv + 2 * d}, {g.kq, ldq, g.kq, ldq},
-                           {dqkv + 3 * d, xn + d, dqkv + 3 * d + 16, xn + d + 16}, {ldq, g.kq, ldq, g.kq},
+        const OuterJobs oj{{xn, dqkv, xn, dqkv + 3 * q - d}, {g.kq, ldq, g.kq, ldq},
+                           {dqkv + 3 * q, xn + d, dqkv + 3 * q + 16, xn + d + 16}, {ldq, g.kq, ldq, g.kq},
                            {G[0], G[1], G[2], G[3]}, {1, r, 1, r}, {d, 1, d, 1}};   // dA_q, dB_q, dA_v, dB_v
         LSAM_TRY(launch_outer_reduce4<T>(oj, M, d, r, part, s));
         if (g.need_dx) {
@@ -540,8 +553,12 @@ int lsam_hiera_create(const lsam_hiera_config_t* c, lsam_hiera_t** out) {
         } else if (g.pool == 2 && (g.ws <= 0 || g.ws % 2 || g.gin % 2)) {
             set_error("hiera_create: q-pool block %d needs an even window and grid", i);
             rc = LSAM_ERR_UNSUPPORTED;
-        } else if (g.lora && (g.dim != g.dout || g.pool != 1 || g.ws <= 0 || g.ws * g.ws > 64)) {
-            set_error("hiera_create: LoRA block %d must be a same-width windowed block with <= 64 keys", i);
+        } else if (g.lora && (g.ws <= 0 || (g.ws / g.pool) * (g.ws / g.pool) > 64)) {
+            set_error("hiera_create: LoRA block %d must be a windowed block with <= 64 queries per window", i);
+            rc = LSAM_ERR_UNSUPPORTED;
+        } else if (g.lora && g.need_dx && (g.dim != g.dout || g.pool != 1)) {
+            set_error("hiera_create: a stage-entry block (dim != dim_out / q-pool) can only be the FIRST LoRA block "
+                      "(block %d): no gradient path through its pooled shortcut is built", i);
             rc = LSAM_ERR_UNSUPPORTED;
         }
     }

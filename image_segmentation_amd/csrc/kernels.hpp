@@ -72,6 +72,7 @@ struct AttnBwdArgs {
     const float* lse;
     void* dqkv; int lddqkv;
     int N, H, W, ws, nh, hd;
+    int pool = 1;   // 2: q was max-pooled 2x2 inside each window; dout / lse are then indexed by the pooled (output) tokens
 };
 template <typename T> int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t s);
 

@@ -130,14 +130,19 @@ def attention_fwd(qkv: torch.Tensor, bias: torch.Tensor, ws: int, pool: int, nh:
 
 
 def attention_bwd(qkv: torch.Tensor, bias: torch.Tensor, dout_t: torch.Tensor, lse: torch.Tensor,
-                  ws: int, nh: int, ld_out: Optional[int] = None) -> torch.Tensor:
+                  ws: int, nh: int, ld_out: Optional[int] = None, pool: int = 1) -> torch.Tensor:
+    """dqkv [N,H,W,ld] from dout [N,H/pool,W/pool,d] (see lsam_attention_bwd / lsam_attention_bwd_qpool)."""
     _need_gpu(qkv, bias, dout_t, lse)
     N, H, W, C3 = qkv.shape
     d = C3 // 3
     ld = C3 if ld_out is None else ld_out
     dqkv = torch.zeros(N, H, W, ld, dtype=qkv.dtype, device=qkv.device)
-    check(lib().lsam_attention_bwd(dtype_code(qkv.dtype), ptr(qkv), C3, ptr(bias), ptr(dout_t), d,
-                                   ptr(lse), ptr(dqkv), ld, N, H, W, ws, nh, d // nh, stream()))
+    if pool == 1:
+        check(lib().lsam_attention_bwd(dtype_code(qkv.dtype), ptr(qkv), C3, ptr(bias), ptr(dout_t), d,
+                                       ptr(lse), ptr(dqkv), ld, N, H, W, ws, nh, d // nh, stream()))
+    else:
+        check(lib().lsam_attention_bwd_qpool(dtype_code(qkv.dtype), ptr(qkv), C3, ptr(bias), ptr(dout_t), d,
+                                             ptr(lse), ptr(dqkv), ld, N, H, W, ws, pool, nh, d // nh, stream()))
     return dqkv
 
 

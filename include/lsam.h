@@ -100,7 +100,8 @@ int lsam_layernorm_bwd(int dtype, const float* dy, int lddy, const float* x, int
  *        global attention use the LDS-DMA kernel, which fetches pad-token k/v from it
  *   ws   window size, 0 = global;  pool 1 or 2 (2x2 max over q inside each window)
  *   out  T [N, H/pool, W/pool, nh*hd];  lse (nullable) fp32 [N*(H/pool)*(W/pool)][nh]
- * hd % 8 == 0, hd <= 64. */
+ * hd % 8 == 0, hd <= 128 (bf16 windows of 8x8 .. 14x14 and global attention with hd <= 64 take the MFMA/LDS-DMA
+ * kernels; everything else the generic tiled kernel). */
 int lsam_attention_fwd(int dtype, const void* qkv, int ldqkv, const float* bias, const void* bias_t,
                        void* out, int ldo, float* lse, int N, int H, int W, int ws, int pool, int nh,
                        int hd, lsam_stream_t stream);
@@ -112,12 +113,20 @@ int lsam_attention_fwd_pooled_q(int dtype, const void* qkv, int ldqkv, const flo
                                 const float* q_pooled, int ld_qp, void* out, int ldo, float* lse, int N, int H, int W,
                                 int ws, int nh, int hd, lsam_stream_t stream);
 
-/* Backward of the above for un-pooled windows with ws*ws <= 64 (the LoRA blocks):
+/* Backward of the above for the LoRA blocks: windows (ws > 0) with at most 64 queries each and any number of keys,
+ * hd <= 96 (autograd of F.scaled_dot_product_attention, hieradet.py:70-74, as core_loss.backward() walks it):
  *   dout T [N,H,W,nh*hd] -> dqkv T [N,H,W, lddqkv] (q|k|v gradients of the real tokens; the
- *   zero-pad tokens' k/v are constants and get no gradient). */
+ *   zero-pad tokens' k/v are constants and get no gradient).  Every q, k, v element of a real token is written. */
 int lsam_attention_bwd(int dtype, const void* qkv, int ldqkv, const float* bias, const void* dout,
                        int lddo, const float* lse, void* dqkv, int lddqkv, int N, int H, int W,
                        int ws, int nh, int hd, lsam_stream_t stream);
+/* The same with Hiera's q-pool (pool = 2; pool = 1 is lsam_attention_bwd): dout T [N,H/2,W/2,nh*hd] and
+ * lse [N*(H/2)*(W/2)][nh] are indexed by the pooled tokens, qkv / dqkv by the input tokens.  The gradient of a pooled
+ * query goes, per channel, to the first maximal token of its 2x2 group (autograd of nn.MaxPool2d in do_pool,
+ * hieradet.py:25-36,64-67); the other three receive 0.  (ws/2)^2 <= 64, ws and the grid even. */
+int lsam_attention_bwd_qpool(int dtype, const void* qkv, int ldqkv, const float* bias, const void* dout,
+                             int lddo, const float* lse, void* dqkv, int lddqkv, int N, int H, int W,
+                             int ws, int pool, int nh, int hd, lsam_stream_t stream);
 
 /* out[n,h/2,w/2,:] = max over the 2x2 block (do_pool on the shortcut, hieradet.py:140). fp32 NHWC. */
 int lsam_maxpool2x2(const float* x, float* out, int N, int H, int W, int C, lsam_stream_t stream);

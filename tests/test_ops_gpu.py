@@ -203,6 +203,28 @@ def test_attention_bwd(ops, dt, H, ws, nh):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("H,ws,pool,nh,hd", [
+    (16, 8, 1, 2, 72), (18, 7, 1, 2, 96),          # Hiera-L (72) and Hiera-T/S (96) heads, same-width LoRA blocks
+    (16, 14, 2, 2, 56), (32, 14, 2, 4, 96),        # stage-entry block: 49 pooled queries x 196 keys (4 key tiles), padded grid
+    (32, 16, 2, 2, 72), (16, 8, 2, 2, 56), (8, 4, 2, 1, 56),
+])
+def test_attention_bwd_general(ops, dt, H, ws, pool, nh, hd):
+    """The tiled backward: head_dim up to 96, any number of keys, 2x2 q-pool with the gradient routed to the argmax token."""
+    N = 2
+    # values rounded to multiples of 1/8 would tie inside 2x2 groups; keep them generic and compare against autograd of
+    # the oracle's max-pool, whose tie rule (first maximum) the kernel follows
+    qkv = rnd(N, H, H, 3 * nh * hd, seed=3 + hd).cuda().to(dt)
+    bias = (rnd(3 * nh * hd, seed=9) * 0.5).cuda()
+    do = rnd(N, H // pool, H // pool, nh * hd, seed=4).cuda().to(dt)
+    _, lse = ops.attention_fwd(qkv, bias, ws, pool, nh, want_lse=True)
+    dqkv = ops.attention_bwd(qkv, bias, do, lse, ws, nh, pool=pool)
+    x = qkv.float().cpu().double().requires_grad_(True)
+    ref, _ = ref_attention(x, bias.to(dt).float().cpu(), H, H, ws, pool, nh)
+    (ref * do.float().cpu().double()).sum().backward()
+    assert rel_err(dqkv.float(), x.grad) < tol(dt, 2e-5, 1e-2)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("H,ws,nh", [(16, 8, 2), (32, 16, 4), (32, 4, 4), (28, 14, 8), (64, 14, 2)])
 def test_attention_fwd_with_pooled_queries(ops, dt, H, ws, nh):
     """do_pool(q) (hieradet.py:69-71) handed in instead of being taken from qkv: every forward kernel, bit for bit;
