@@ -29,6 +29,7 @@ class _Bucket:
             o += p.numel()
         self.work = None      # in-flight all-reduce started by the hook
         self.filled = False   # flat holds this step's local gradients
+        self.pending = []     # (increment buffer, work) of further backwards before reduce()
 
 
 class LoRAGradReducer:
@@ -52,6 +53,7 @@ class LoRAGradReducer:
             o += n
         self.views = [v for b in self.buckets for v in b.views]
         self._by_first = {id(b.params[0]): b for b in self.buckets}
+        self._invalidate = []   # trunks whose packed weights must be refreshed after parameters change through .data
 
     def world_size(self) -> int:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
@@ -59,6 +61,9 @@ class LoRAGradReducer:
     def attach(self, trunk) -> "LoRAGradReducer":
         """Overlap mode: the trunk's backward hands each LoRA block's gradients to on_bucket()."""
         trunk.set_grad_bucket_hook(self.on_bucket)
+        inv = getattr(trunk, "invalidate_packed", None)
+        if inv is not None:
+            self._invalidate.append(inv)
         return self
 
     @torch.no_grad()
@@ -70,6 +75,8 @@ class LoRAGradReducer:
         torch._foreach_copy_(self.views, [p.data for p in self.params])
         dist.broadcast(self.flat, src=src, group=self.group)
         torch._foreach_copy_([p.data for p in self.params], self.views)
+        for inv in self._invalidate:
+            inv()
 
     @torch.no_grad()
     def on_bucket(self, params, grads):
@@ -79,6 +86,19 @@ class LoRAGradReducer:
         if b is None or len(params) != len(b.params) or any(p is not q for p, q in zip(params, b.params)):
             return   # not one of our buckets: reduce() falls back to .grad
         if self.world_size() == 1:
+            return
+        if b.filled:
+            # a second backward before reduce() (gradient accumulation, two views per step): DDP sums the micro-batches.
+            # The first all-reduce may still be in flight on b.flat, so the increment gets a staging buffer of its own
+            # and is reduced separately: sum_r(g1_r) + sum_r(g2_r) = sum_r(g1_r + g2_r); reduce() adds them up.
+            inc = torch.empty_like(b.flat)
+            o = 0
+            views = []
+            for p in b.params:
+                views.append(inc[o:o + p.numel()].view_as(p))
+                o += p.numel()
+            torch._foreach_copy_(views, list(grads))
+            b.pending.append((inc, dist.all_reduce(inc, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
             return
         torch._foreach_copy_(b.views, list(grads))
         b.filled = True
@@ -97,6 +117,10 @@ class LoRAGradReducer:
                 b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         for b in reversed(self.buckets):
             b.work.wait()
+            for inc, work in b.pending:
+                work.wait()
+                b.flat.add_(inc)
+            b.pending = []
             b.work, b.filled = None, False
         self.flat.mul_(1.0 / ws)
         for p, v in zip(self.params, self.views):

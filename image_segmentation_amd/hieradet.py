@@ -194,6 +194,7 @@ class _Plan:
             self.stage_info.append((c.value, g.value))
         self.arena = torch.empty(lib().lsam_hiera_arena_bytes(h), dtype=torch.uint8, device=device)
         self.packed_sig = None
+        self.lora_gen = 0        # bumped by every pack_lora: which factors the arena's LoRA slices hold
         self.ws_pool = {}
         self.bucket_hook = trunk._grad_bucket_hook
 
@@ -206,7 +207,7 @@ class _Plan:
             pass
 
     def signature(self, trunk: "Hiera"):
-        return tuple((p.data_ptr(), p._version) for p in trunk._frozen_params())
+        return (trunk._pack_epoch,) + tuple((p.data_ptr(), p._version) for p in trunk._frozen_params())
 
     def pack(self, trunk: "Hiera"):
         from .lora_qkv import LoRA_qkv
@@ -248,6 +249,7 @@ class _Plan:
         for i in range(self.n_lora):
             lp[i].a_q, lp[i].b_q, lp[i].a_v, lp[i].b_v = (ptr(t) for t in lora_params[4 * i: 4 * i + 4])
         check(lib().lsam_hiera_pack_lora(self.h, lp, self.arena.data_ptr(), stream()))
+        self.lora_gen += 1
 
     def workspace(self, batch: int, with_grad: bool) -> torch.Tensor:
         key = (batch, with_grad)
@@ -279,11 +281,15 @@ class _TrunkFn(torch.autograd.Function):
         check(lib().lsam_hiera_forward(plan.h, img.data_ptr(), N, arr, plan.arena.data_ptr(), ws.data_ptr(),
                                        ws.numel(), int(with_grad), stream()))
         ctx.plan, ctx.N, ctx.with_grad = plan, N, with_grad
+        ctx.lora_gen = plan.lora_gen
         # no zero tensors for the stage outputs nothing differentiates through (0.8 GB of fills per step at batch 16)
         ctx.set_materialize_grads(False)
         if with_grad:
             ctx.ws = ws
             ctx.lora_shapes = [tuple(t.shape) for t in lora]
+            # this step's factors in one flat copy (one small launch): the backward restores them if another forward
+            # re-packs the plan's LoRA slices in between
+            ctx.lora_flat = torch.cat([t.reshape(-1) for t in lora_c]) if lora_c else None
             ctx.lora_params = lora   # the Parameters themselves: handed to the gradient-bucket hook
             ctx.mark_non_differentiable(*outs[:-1])
         else:
@@ -302,7 +308,19 @@ class _TrunkFn(torch.autograd.Function):
         g = g.to(torch.float32).contiguous()
         out = [torch.empty(s, dtype=torch.float32, device=g.device) for s in ctx.lora_shapes]
         arr = (C.c_void_p * len(out))(*[o.data_ptr() for o in out])
-        # the plan's LoRA-dependent packed operands still hold this step's factors
+        # The backward reads LoRA-dependent packed operands (B^T, the A columns of W_qkv^T, [A_q; A_v]) from the plan's
+        # arena.  Another forward between this step's forward and its backward (a teacher / eval pass with other
+        # factors, LoRABank.activate) re-packed them: restore this step's factors first, from the copy the forward kept.
+        if plan.lora_gen != ctx.lora_gen:
+            parts, o = [], 0
+            for shp in ctx.lora_shapes:
+                n = 1
+                for v in shp:
+                    n *= v
+                parts.append(ctx.lora_flat[o:o + n].view(shp))
+                o += n
+            plan.pack_lora(parts)
+            ctx.lora_gen = plan.lora_gen
         hook = plan.bucket_hook
         if hook is None:
             check(lib().lsam_hiera_backward(plan.h, g.data_ptr(), ctx.N, arr, plan.arena.data_ptr(),
@@ -372,6 +390,16 @@ class Hiera(nn.Module):
         self.compute_dtype: Optional[torch.dtype] = None
         self._plans = {}
         self._grad_bucket_hook = None
+        self._pack_epoch = 0
+        # loaders rewrite parameters in place, some through `.data` (which bumps no version counter): re-pack after any load
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed())
+
+    def invalidate_packed(self):
+        """Force the packed-weight arenas to be rebuilt on the next forward.  The trunk re-packs by itself when a frozen
+        parameter is replaced or modified through autograd-visible in-place ops (data_ptr / _version change) and after
+        load_state_dict; call this after editing frozen parameters through `.data` (EMA code, custom loaders,
+        dp.LoRAGradReducer.broadcast_params does it for you)."""
+        self._pack_epoch += 1
 
     def set_grad_bucket_hook(self, hook):
         """hook(params, grads) is called from the backward as soon as one LoRA block's gradients are
@@ -409,9 +437,13 @@ class Hiera(nn.Module):
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != x.shape[3]:
             raise _C.LsamError(f"expected frames [N,3,S,S], got {tuple(x.shape)}")
         dt = _compute_dtype(self.compute_dtype)
-        key = (dt, x.shape[-1], x.device, tuple(type(b.attn.qkv).__name__ for b in self.blocks[-4:]))
+        wrapped = tuple(type(b.attn.qkv).__name__ for b in self.blocks)
+        key = (dt, x.shape[-1], x.device, wrapped)
         plan = self._plans.get(key)
         if plan is None:
+            # plans of a superseded module tree (the model was wrapped after a first forward) are dropped with their arenas
+            for k in [k for k in self._plans if k[3] != wrapped]:
+                del self._plans[k]
             plan = _Plan(self, dt, x.shape[-1], x.device)
             self._plans[key] = plan
         if plan.packed_sig != plan.signature(self):

@@ -21,6 +21,28 @@ def _need_gpu(*ts):
                                "there is no CPU fallback")
 
 
+def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """A vector / matrix argument the kernels read as contiguous fp32 (biases, LayerNorm parameters and statistics,
+    residuals): module Parameters after `model.half()` / `.to(bfloat16)`, or non-contiguous views, are converted
+    instead of being read as garbage.  No copy when the tensor already qualifies."""
+    if t is None:
+        return None
+    t = t.detach()
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.to(torch.float32).contiguous()
+    return t
+
+
+def _f32rows(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """fp32 2-D tensor with contiguous rows (a leading dimension is passed separately)."""
+    if t is None:
+        return None
+    t = t.detach()
+    if t.dtype != torch.float32 or t.stride(-1) != 1:
+        t = t.to(torch.float32).contiguous()
+    return t
+
+
 def _rows2d(t: torch.Tensor) -> Tuple[int, int, int]:
     """(rows, cols, ld) of a 2-D tensor whose rows are contiguous."""
     assert t.dim() == 2 and t.stride(1) == 1, "expect row-major 2-D tensor"
@@ -46,6 +68,7 @@ def linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None
     """out = epilogue(A[:, :K] @ W[:N, :K].T + bias) + res   (see lsam_linear)."""
     _need_gpu(A, W, bias, res)
     assert A.dtype == W.dtype
+    bias, res = _f32c(bias), _f32rows(res)
     M, Ka, lda = _rows2d(A)
     Nw, Kw, ldw = _rows2d(W)
     K = min(Ka, Kw) if K is None else K
@@ -82,6 +105,7 @@ def linear_maxpool2x2(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, n_im
 def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, dtype: torch.dtype,
                   ld: Optional[int] = None, want_stats: bool = False, eps: float = 1e-6):
     _need_gpu(x, gamma, beta)
+    x, gamma, beta = _f32rows(x), _f32c(gamma), _f32c(beta)
     M, Cc, ldx = _rows2d(x)
     ld = Cc if ld is None else ld
     y = torch.zeros(M, ld, dtype=dtype, device=x.device) if ld != Cc else \
@@ -95,6 +119,7 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, dtyp
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor,
                   dres: Optional[torch.Tensor], dtype: torch.dtype):
     _need_gpu(dy, x, stats, gamma, dres)
+    dy, x, stats, gamma, dres = _f32rows(dy), _f32rows(x), _f32c(stats), _f32c(gamma), _f32rows(dres)
     M, Cc, lddy = _rows2d(dy)
     dx = torch.empty(M, Cc, dtype=torch.float32, device=x.device)
     dxt = torch.empty(M, Cc, dtype=dtype, device=x.device)
@@ -109,6 +134,7 @@ def attention_fwd(qkv: torch.Tensor, bias: torch.Tensor, ws: int, pool: int, nh:
     """qkv T [N,H,W,3*nh*hd] (contiguous) -> out T [N,H/pool,W/pool,nh*hd] (+ lse fp32 [N,H',W',nh]).
     q_pooled (pool == 2 only): fp32 [N,H/2,W/2,nh*hd], the pooled queries; qkv's q columns are then not read."""
     _need_gpu(qkv, bias)
+    bias = _f32c(bias)
     assert qkv.dim() == 4 and qkv.is_contiguous()
     N, H, W, C3 = qkv.shape
     dout = C3 // 3
@@ -133,6 +159,7 @@ def attention_bwd(qkv: torch.Tensor, bias: torch.Tensor, dout_t: torch.Tensor, l
                   ws: int, nh: int, ld_out: Optional[int] = None, pool: int = 1) -> torch.Tensor:
     """dqkv [N,H,W,ld] from dout [N,H/pool,W/pool,d] (see lsam_attention_bwd / lsam_attention_bwd_qpool)."""
     _need_gpu(qkv, bias, dout_t, lse)
+    bias, lse = _f32c(bias), _f32c(lse)
     N, H, W, C3 = qkv.shape
     d = C3 // 3
     ld = C3 if ld_out is None else ld_out
@@ -217,6 +244,7 @@ def window_block_pack(qkv_w, qkv_b, proj_w, proj_b, nh: int):
 def window_block_fwd(x, norm1_w, norm1_b, img, bias, nh: int, eps: float = 1e-6, out=None):
     """y = x + proj(attn(qkv(LN1(x)))) for x fp32 [N,H,W,d] with 8x8 windows (see lsam_window_block_fwd)."""
     _need_gpu(x, norm1_w, norm1_b, img, bias)
+    norm1_w, norm1_b = _f32c(norm1_w), _f32c(norm1_b)
     assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
     N, H, W, d = x.shape
     y = torch.empty_like(x) if out is None else out
@@ -241,6 +269,7 @@ def mlp_block_pack(fc1_w, fc1_b, fc2_w, fc2_b):
 def mlp_block_fwd(x, norm2_w, norm2_b, img, bias, eps: float = 1e-6, out=None):
     """y = x + fc2(GELU(fc1(LN2(x)))) for x fp32 [M, d] (see lsam_mlp_block_fwd)."""
     _need_gpu(x, norm2_w, norm2_b, img, bias)
+    norm2_w, norm2_b = _f32c(norm2_w), _f32c(norm2_b)
     assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
     M, d = x.shape
     y = torch.empty_like(x) if out is None else out
@@ -252,6 +281,7 @@ def mlp_block_fwd(x, norm2_w, norm2_b, img, bias, eps: float = 1e-6, out=None):
 def mlp_block_fwd_next_norm(x, norm2_w, norm2_b, img, bias, next_norm_w, next_norm_b, eps: float = 1e-6):
     """(y, LayerNorm_next(y) as bf16): lsam_mlp_block_fwd plus the following block's norm1 from the same registers."""
     _need_gpu(x, norm2_w, norm2_b, img, bias, next_norm_w, next_norm_b)
+    norm2_w, norm2_b, next_norm_w, next_norm_b = _f32c(norm2_w), _f32c(norm2_b), _f32c(next_norm_w), _f32c(next_norm_b)
     assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
     M, d = x.shape
     y = torch.empty_like(x)

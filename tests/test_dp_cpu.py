@@ -61,8 +61,15 @@ def _worker(rank, world, port, q, overlap):
             local = [prm.grad for prm in params]
             for prm in params:
                 prm.grad = None
-            for lo in (4, 0):
-                red.on_bucket(params[lo:lo + 4], local[lo:lo + 4])
+            if overlap == "accum":
+                # gradient accumulation: two backwards before reduce(); DDP sums the micro-batches
+                for frac in (0.25, 0.75):
+                    for lo in (4, 0):
+                        red.on_bucket(params[lo:lo + 4], [frac * g for g in local[lo:lo + 4]])
+                assert all(len(b.pending) == 1 for b in red.buckets)
+            else:
+                for lo in (4, 0):
+                    red.on_bucket(params[lo:lo + 4], local[lo:lo + 4])
             assert all(b.work is not None for b in red.buckets)
             for prm, g in zip(params, local):
                 prm.grad = g
@@ -80,7 +87,7 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("overlap", [False, True, "accum"])
 def test_two_rank_lora_grad_allreduce_matches_global_batch(overlap):
     world = 2
     ctx = mp.get_context("spawn")

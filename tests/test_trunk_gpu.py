@@ -334,3 +334,43 @@ def test_lora_bank_teacher_pass_matches_a_model_built_with_those_factors():
         assert torch.equal(got, want)
         bank.activate("curr")
         assert torch.equal(enc(img)["vision_features"], own)
+
+
+def test_backward_after_an_interleaved_forward_with_other_factors():
+    """A teacher / eval forward with OTHER LoRA factors between a student forward and its backward re-packs the plan's
+    LoRA slices; the backward must restore the student's factors (gradients = those of the undisturbed step)."""
+    import image_segmentation_amd as m
+    from image_segmentation_amd.synth import synth_frames
+    img = synth_frames(2, 256, 0, device="cuda")
+    enc = make_encoder(TINY)
+    fpn_loss(enc(img)).backward()
+    torch.cuda.synchronize()
+    want = {n: p.grad.detach().clone() for n, p in enc.named_parameters() if p.requires_grad}
+    for p in enc.parameters():
+        p.grad = None
+    bank = m.LoRABank(enc)
+    bank.store("student")
+    bank.load_state_dict("teacher", {n: (-0.5 * p.detach() + 0.01) for n, p in enc.named_parameters()
+                                     if "linear_a_" in n or "linear_b_" in n})
+    loss = fpn_loss(enc(img))                      # student forward (graph kept)
+    bank.activate("teacher")                       # in-place swap of the parameter VALUES ...
+    with torch.no_grad():
+        enc(img)                                   # ... and a teacher pass that re-packs the plan
+    bank.activate("student")
+    loss.backward()
+    torch.cuda.synchronize()
+    for n, p in enc.named_parameters():
+        if p.requires_grad:
+            assert torch.equal(p.grad, want[n]), n
+
+
+def test_unit_ops_accept_half_precision_module_parameters():
+    """Parameters after model.to(bfloat16) or non-contiguous vectors must be converted, not read as garbage."""
+    from image_segmentation_amd import ops
+    x = torch.randn(64, 112, device="cuda")
+    g, b = torch.randn(112, device="cuda"), torch.randn(112, device="cuda")
+    want = ops.layernorm_fwd(x, g.bfloat16().float(), b.bfloat16().float(), torch.float32)
+    got = ops.layernorm_fwd(x, g.bfloat16(), b.bfloat16(), torch.float32)
+    assert torch.equal(got, want)
+    g2 = torch.stack([g, g], 1)[:, 0]              # stride-2 view
+    assert torch.equal(ops.layernorm_fwd(x, g2, b, torch.float32), ops.layernorm_fwd(x, g, b, torch.float32))
