@@ -99,6 +99,11 @@ def lib() -> C.CDLL:
                      "lsam_tail_block_image_bytes", "lsam_tail_block_vec_floats", "lsam_patch_embed_image_bytes"):
             getattr(L, name).argtypes = [i]
         L.lsam_lateral_conv_image_bytes.argtypes = [i, i]
+        L.lsam_neck_conv_image_bytes.restype = C.c_size_t
+        L.lsam_neck_conv_image_bytes.argtypes = [i, i, i]
+        L.lsam_neck_conv_pack.argtypes = [i, vp, i, i, vp, vp]
+        L.lsam_neck_level_fwd.argtypes = [i, vp, vp, vp, vp, vp, i, i, i, i, i, vp]
+        L.lsam_neck_topdown_bwd.argtypes = [i, vp, vp, vp, i, i, i, i, vp]
         L.lsam_lateral_conv_pack.argtypes = [vp, i, i, vp, vp]
         L.lsam_lateral_conv_fwd.argtypes = [vp, vp, vp, vp, i, i, i, vp]
         L.lsam_patch_embed_pack.argtypes = [vp, i, vp, vp]
@@ -149,5 +154,6 @@ EXPORTED = [
     "lsam_mlp_block_fwd", "lsam_tail_block_image_bytes", "lsam_tail_block_vec_floats", "lsam_tail_block_pack",
     "lsam_tail_block_fwd", "lsam_patch_embed_image_bytes", "lsam_patch_embed_pack", "lsam_patch_embed_fwd", "lsam_linear_maxpool2x2",
     "lsam_lateral_conv_image_bytes", "lsam_lateral_conv_pack", "lsam_lateral_conv_fwd", "lsam_mlp_block_fwd_next_norm", "lsam_attention_fwd_pooled_q",
-    "lsam_attention_bwd_qpool", "lsam_outer_reduce_static_max_ws", "lsam_outer_reduce_static_init", "lsam_outer_reduce_static",
+    "lsam_attention_bwd_qpool", "lsam_neck_conv_image_bytes", "lsam_neck_conv_pack", "lsam_neck_level_fwd",
+    "lsam_neck_topdown_bwd", "lsam_outer_reduce_static_max_ws", "lsam_outer_reduce_static_init", "lsam_outer_reduce_static",
 ]

@@ -2,6 +2,6 @@
 `LoRA_qkv` / `image_encoder` module API).  Arithmetic lives in csrc/ (HIP, gfx950) behind
 the C ABI of include/lsam.h; these modules are the host-side mirror of the reference API."""
 from .hieradet import Hiera, MultiScaleAttention, MultiScaleBlock, PatchEmbed, MLP  # noqa: F401
-from .image_encoder import FpnNeck, ImageEncoder, PositionEmbeddingSine, build_image_encoder  # noqa: F401
+from .image_encoder import FpnNeck, ImageEncoder, PositionEmbeddingSine, build_image_encoder, forward_image  # noqa: F401
 from .lora_qkv import (LoRA_qkv, LoRABank, custom_load_lora_parameters, custom_save_lora_parameters,  # noqa: F401
                        wrap_image_encoder_lora)

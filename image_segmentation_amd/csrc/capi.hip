@@ -148,6 +148,27 @@ int lsam_lateral_conv_fwd(const float* x, const void* image, const float* bias, 
     return launch_lateral(x, image, bias, out, M, in_channels, out_channels, static_cast<hipStream_t>(stream));
 }
 
+size_t lsam_neck_conv_image_bytes(int dtype, int in_channels, int out_channels) {
+    return neck_image_bytes(in_channels, out_channels, dtype == LSAM_BF16 ? 2 : 4);
+}
+int lsam_neck_conv_pack(int dtype, const float* weight, int in_channels, int out_channels, void* image, lsam_stream_t stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DISPATCH(dtype, launch_pack_neck<float>(weight, in_channels, out_channels, image, s),
+             launch_pack_neck<bf16>(weight, in_channels, out_channels, image, s));
+}
+int lsam_neck_level_fwd(int dtype, const float* x, const void* image, const float* bias, const void* top, void* out, int N,
+                        int H, int W, int in_channels, int out_channels, lsam_stream_t stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DISPATCH(dtype, launch_neck_level<float>(x, image, bias, top, out, N, H, W, in_channels, out_channels, s),
+             launch_neck_level<bf16>(x, image, bias, top, out, N, H, W, in_channels, out_channels, s));
+}
+int lsam_neck_topdown_bwd(int dtype, const void* g_fine, const void* g_coarse, void* out, int N, int Hc, int Wc, int C,
+                          lsam_stream_t stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DISPATCH(dtype, launch_neck_topdown_bwd<float>(g_fine, g_coarse, out, N, Hc, Wc, C, s),
+             launch_neck_topdown_bwd<bf16>(g_fine, g_coarse, out, N, Hc, Wc, C, s));
+}
+
 size_t lsam_window_block_image_bytes(int nh) { return (nh == 1 || nh == 2) ? winblock_image_bytes(nh) : 0; }
 size_t lsam_window_block_bias_floats(int nh) { return (nh == 1 || nh == 2) ? winblock_bias_floats(nh) : 0; }
 int lsam_window_block_pack(const float* qkv_w, const float* qkv_b, const float* proj_w, const float* proj_b, int nh,

@@ -96,6 +96,16 @@ size_t lateral_image_bytes(int K, int N);
 int launch_pack_lateral(const float* w, int K, int N, void* img, hipStream_t s);
 int launch_lateral(const float* x, const void* img, const float* bias, void* out, int M, int K, int N, hipStream_t s);
 
+// FPN neck level: lateral 1x1 conv (+ nearest-x2 top-down add) from the fp32 stage output, T out (neck.hip)
+bool neck_level_supported(int K, int N);
+size_t neck_image_bytes(int K, int N, size_t esz);
+template <typename T> int launch_pack_neck(const float* w, int K, int N, void* img, hipStream_t s);
+template <typename T>
+int launch_neck_level(const float* x, const void* img, const float* bias, const void* top, void* out, int Nimg, int H, int W,
+                      int K, int N, hipStream_t s);
+template <typename T>
+int launch_neck_topdown_bwd(const void* gf, const void* gc, void* out, int Nimg, int Hc, int Wc, int C, hipStream_t s);
+
 // fused attention half of a same-dim 8x8-window block (winblock.hip)
 struct WinBlockArgs {
     const float* x;       // [N*H*W][D] fp32 residual stream (D = nh * hd)

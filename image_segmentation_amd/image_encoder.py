@@ -2,10 +2,13 @@
 (SAM2/sam2/sam2/modeling/backbones/image_encoder.py) and PositionEmbeddingSine
 (SAM2/sam2/sam2/modeling/position_encoding.py:16-124, the `_pe` path only).
 
-The 1x1 lateral convs run on the NHWC trunk outputs as `lsam_linear` GEMMs (bias fused),
-with an input-gradient-only autograd rule (the neck is frozen by wrap_image_encoder_lora,
-lora_qkv.py:159-160).  The nearest-x2 top-down add stays a PyTorch elementwise op in this
-round (SURVEY.md section 8f row 1 lists the fully native neck as the next widening step).
+Every FPN level is ONE HIP kernel on the NHWC trunk output: lateral 1x1 conv + bias + nearest-x2
+top-down add (`lsam_neck_level_fwd` / `lsam_lateral_conv_fwd`), with packed weights cached on the
+module; the backward is the top-down adjoint plus one input-gradient GEMM for the last stage only
+(the neck is frozen by wrap_image_encoder_lora, lora_qkv.py:159-160).  `forward_image` mirrors
+SAM2Base.forward_image (sam2_base.py:467-479) including mask_decoder.conv_s0 / conv_s1, which are
+composed with the lateral convolutions of levels 0 / 1 into single 112 -> 32 / 224 -> 64 kernels.
+No PyTorch arithmetic remains in the encoder's forward or backward.
 """
 from __future__ import annotations
 
@@ -14,7 +17,6 @@ from typing import List, Optional
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
 from ._C import LsamError
@@ -73,33 +75,91 @@ class PositionEmbeddingSine(nn.Module):
         return self.cache[key][None].expand(B, -1, -1, -1)
 
 
-class _Conv1x1Fn(torch.autograd.Function):
-    """y[NHWC] = x[NHWC] . W^T + b on MFMA; backward gives dx only (W, b frozen)."""
+class _NeckPack:
+    """Packed operands of one FpnNeck for one (dtype, device): a weight image per level for the forward kernel, fp32
+    biases, and -- for the level the LoRA gradient passes through -- the transposed weight for dx = g . W.  Built once
+    and rebuilt only when a conv parameter changes (data_ptr / _version) or `invalidate_packed()` is called."""
+
+    def __init__(self, neck: "FpnNeck", dt: torch.dtype, device: torch.device):
+        self.sig = neck._pack_signature()
+        self.img, self.bias, self.lat_img = [], [], []
+        for seq in neck.convs:
+            w, b = seq.conv.weight.detach(), seq.conv.bias.detach()
+            w = w.to(device=device, dtype=torch.float32).reshape(w.shape[0], w.shape[1]).contiguous()
+            co, K = w.shape
+            use_lateral = dt == torch.bfloat16 and ops.lateral_conv_supported(K, co)
+            # bf16, K <= 224 (the two high-resolution levels): the LDS-resident-weight kernel of lateral.hip
+            self.lat_img.append(ops.lateral_conv_pack(w) if use_lateral else None)
+            self.img.append(None if use_lateral else ops.neck_conv_pack(w, dt))
+            self.bias.append(b.to(device=device, dtype=torch.float32).contiguous())
+        wl = neck.convs[0].conv.weight.detach()     # convs[0] serves the LAST (coarsest) level: convs[n - i], image_encoder.py:114
+        self.wT_last = ops.pack_matrix(wl.to(device=device, dtype=torch.float32).reshape(wl.shape[0], wl.shape[1]).t(), dt)
+
+
+class _NeckFn(torch.autograd.Function):
+    """The whole FPN neck (image_encoder.py:102-134) as one autograd node: one HIP kernel per level in the forward
+    (lateral 1x1 conv + bias + nearest-x2 top-down add, T NHWC out).  The neck is frozen (lora_qkv.py:159-160) and
+    only the LAST stage output carries a gradient (the LoRA blocks; hieradet.py:306-334 runs the other stages under
+    no_grad), so the backward is the top-down chain's adjoint into the coarsest level followed by ONE GEMM
+    dx_last = g_last . W_last -- no weight gradient, no input gradient for the other levels."""
 
     @staticmethod
-    def forward(ctx, x_nhwc, weight, bias, dt):
-        N, H, W, Cc = x_nhwc.shape
-        co = weight.shape[0]
-        if dt == torch.bfloat16 and x_nhwc.dtype == torch.float32 and ops.lateral_conv_supported(Cc, co):
-            # high-resolution levels: one kernel from the fp32 stage output (no bf16 copy of x in memory)
-            out = ops.lateral_conv(x_nhwc.reshape(-1, Cc), weight, bias)
-        else:
-            xt = ops.cast(x_nhwc.reshape(-1, Cc), dt)
-            wt = ops.pack_matrix(weight.detach().reshape(co, Cc), dt)
-            out = ops.linear(xt, wt, bias.detach())
-        ctx.save_for_backward(weight)
-        ctx.dt, ctx.shape = dt, (N, H, W, Cc)
-        return out.view(N, H, W, co)
+    def forward(ctx, neck, pack, dt, base, *xs):
+        # xs = the stage outputs of levels base .. last (base > 0: forward_image computes the finer levels elsewhere)
+        n = len(xs) - 1
+        outs = [None] * (n + 1)
+        prev = None
+        ctx.chain = []            # (local) levels, fine -> coarse, whose gradient flows into the next coarser one
+        dep = [False] * (n + 2)
+        for i in range(n, -1, -1):
+            x = xs[i]
+            co = neck.d_model
+            top = prev if ((base + i) in neck.fpn_top_down_levels and prev is not None) else None
+            j = n - i             # convs[n_levels - 1 - level] (image_encoder.py:114): index from the coarse end
+            if pack.lat_img[j] is not None and top is None:
+                N, H, W, K = x.shape
+                out = ops.lateral_conv_fwd(x.reshape(-1, K), pack.lat_img[j], pack.bias[j], co).view(N, H, W, co)
+            else:
+                img = pack.img[j] if pack.img[j] is not None else None
+                if img is None:
+                    img = pack.img[j] = ops.neck_conv_pack(neck.convs[j].conv.weight.detach().float(), dt)
+                out = ops.neck_level_fwd(x, img, pack.bias[j], dt, co, top)
+            if top is not None:
+                ctx.chain.append(i)
+            # only levels fed (through top-down adds) by the LAST stage output depend on a differentiable input
+            dep[i] = i == n or (top is not None and dep[i + 1])
+            outs[i] = prev = out
+        ctx.pack, ctx.dt, ctx.n = pack, dt, n
+        ctx.x_last_shape = tuple(xs[n].shape)
+        ctx.set_materialize_grads(False)
+        # the others must not make autograd differentiate the loss with respect to them (0.5 GB maps at level 0)
+        ctx.mark_non_differentiable(*[o for i, o in enumerate(outs) if not dep[i]])
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, g):
-        (weight,) = ctx.saved_tensors
-        N, H, W, Cc = ctx.shape
-        co = weight.shape[0]
-        gt = ops.cast(g.reshape(-1, co).float().contiguous(), ctx.dt)
-        wT = ops.pack_matrix(weight.detach().reshape(co, Cc).t(), ctx.dt)   # [C, co]
-        dx = ops.linear(gt, wT, out_f32=True)
-        return dx.view(N, H, W, Cc), None, None, None
+    def backward(ctx, *gs):
+        n, dt = ctx.n, ctx.dt
+        none = (None, None, None, None) + (None,) * (n + 1)
+        if not ctx.needs_input_grad[4 + n]:
+            return none
+        # gradient arriving at the coarsest level's output: its own plus, through every top-down add between, the 2x2
+        # sums of the finer levels' gradients (prev = lateral + up(prev), so d prev_coarse += sumpool(d prev_fine))
+        g = [None if t is None else t.to(dt).contiguous() for t in gs]
+        carry = None
+        for i in range(0, n + 1):
+            cur = g[i]
+            if carry is not None:
+                cur = carry if cur is None else cur + carry        # (both present only with a loss on several chained levels)
+            carry = None
+            if i < n and (i in ctx.chain) and cur is not None:
+                carry = ops.neck_topdown_bwd(cur)
+            elif i == n:
+                carry = cur
+        if carry is None:
+            return none
+        N, H, W, K = ctx.x_last_shape
+        dx = ops.linear(carry.reshape(-1, carry.shape[-1]), ctx.pack.wT_last, out_f32=True)
+        return (None, None, None, None) + (None,) * n + (dx.view(N, H, W, K),)
 
 
 class FpnNeck(nn.Module):
@@ -111,6 +171,9 @@ class FpnNeck(nn.Module):
         super().__init__()
         if kernel_size != 1 or stride != 1 or padding != 0:
             raise NotImplementedError("the reference factory uses 1x1 lateral convs (sam2_model.py:18-24)")
+        if fpn_interp_model != "nearest" or fuse_type != "sum":
+            raise NotImplementedError("liblsam implements the reference factory's neck: fpn_interp_model='nearest', "
+                                      "fuse_type='sum' (sam2_model.py:22-24)")
         self.position_encoding = position_encoding
         self.convs = nn.ModuleList()
         self.backbone_channel_list = backbone_channel_list
@@ -125,35 +188,47 @@ class FpnNeck(nn.Module):
         if fpn_top_down_levels is None:
             fpn_top_down_levels = range(len(self.convs))
         self.fpn_top_down_levels = list(fpn_top_down_levels)
+        self._packs = {}
+        self._pack_epoch = 0
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed())
+
+    def invalidate_packed(self):
+        """Rebuild the packed conv weights on the next forward (after editing parameters through `.data`)."""
+        self._pack_epoch += 1
+
+    def _pack_signature(self):
+        return (self._pack_epoch,) + tuple((p.data_ptr(), p._version) for p in self.convs.parameters())
+
+    def _pack_for(self, dt: torch.dtype, device: torch.device) -> _NeckPack:
+        key = (dt, device)
+        pack = self._packs.get(key)
+        if pack is None or pack.sig != self._pack_signature():
+            pack = self._packs[key] = _NeckPack(self, dt, device)
+        return pack
+
+    def _nhwc(self, xs: List[torch.Tensor]) -> List[torch.Tensor]:
+        out = []
+        for x in xs:
+            if not x.is_cuda:
+                raise LsamError("FpnNeck runs on the MI355X only (no CPU or PyTorch fallback)")
+            x = x.permute(0, 2, 3, 1)          # the trunk hands out NCHW views of NHWC storage
+            if x.dtype != torch.float32 or not x.is_contiguous():
+                x = x.to(torch.float32).contiguous()
+            out.append(x)
+        return out
 
     def forward(self, xs: List[torch.Tensor]):
-        out = [None] * len(self.convs)
-        pos = [None] * len(self.convs)
         assert len(xs) == len(self.convs)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.convs.parameters()):
+            raise LsamError("FpnNeck parameters must be frozen (wrap_image_encoder_lora does this); "
+                            "liblsam has no weight-gradient GEMM for frozen tensors by design")
         dt = _compute_dtype(None)
-        prev = None
-        n = len(self.convs) - 1
-        for i in range(n, -1, -1):
-            conv = self.convs[n - i].conv
-            if torch.is_grad_enabled() and (conv.weight.requires_grad or conv.bias.requires_grad):
-                raise LsamError("FpnNeck parameters must be frozen (wrap_image_encoder_lora does this); "
-                                "liblsam has no weight-gradient GEMM for frozen tensors by design")
-            x_nhwc = xs[i].permute(0, 2, 3, 1)       # the trunk hands out NCHW views of NHWC storage
-            if not x_nhwc.is_contiguous():
-                x_nhwc = x_nhwc.contiguous()
-            lateral = _Conv1x1Fn.apply(x_nhwc, conv.weight, conv.bias, dt).permute(0, 3, 1, 2)
-            if i in self.fpn_top_down_levels and prev is not None:
-                top_down = F.interpolate(prev.to(dtype=torch.float32), scale_factor=2.0, mode=self.fpn_interp_model,
-                                         align_corners=(None if self.fpn_interp_model == "nearest" else False),
-                                         antialias=False)
-                prev = lateral + top_down
-                if self.fuse_type == "avg":
-                    prev = prev / 2
-            else:
-                prev = lateral
-            out[i] = prev
-            pe_as = getattr(self.position_encoding, "forward_as", None)   # any user module with the reference's API works
-            pos[i] = pe_as(prev) if pe_as is not None else self.position_encoding(prev).to(prev.dtype)
+        xs = self._nhwc(xs)
+        pack = self._pack_for(dt, xs[0].device)
+        feats = _NeckFn.apply(self, pack, dt, 0, *xs)
+        out = [f.permute(0, 3, 1, 2) for f in feats]       # NCHW tensors in channels_last memory
+        pe_as = getattr(self.position_encoding, "forward_as", None)   # any user module with the reference's API works
+        pos = [pe_as(f) if pe_as is not None else self.position_encoding(f).to(f.dtype) for f in out]
         return out, pos
 
 
@@ -174,6 +249,63 @@ class ImageEncoder(nn.Module):
         if self.scalp > 0:
             features, pos = features[: -self.scalp], pos[: -self.scalp]
         return {"vision_features": features[-1], "vision_pos_enc": pos, "backbone_fpn": features}
+
+
+class _HighResPack:
+    def __init__(self, sig, imgs, biases):
+        self.sig, self.imgs, self.biases = sig, imgs, biases
+
+
+def forward_image(model, img_batch: torch.Tensor):
+    """SAM2Base.forward_image (sam2_base.py:467-479) for any object with the reference's attributes: `image_encoder`,
+    `use_high_res_features_in_sam` and `sam_mask_decoder.conv_s0 / conv_s1` (mask_decoder.py:78-81, Conv2d(256, 32, 1) and
+    Conv2d(256, 64, 1)).
+
+    The reference runs the image encoder and then overwrites backbone_fpn[0] / [1] with conv_s0 / conv_s1 of them.  A
+    1x1 convolution of a 1x1 convolution with nothing in between is one 1x1 convolution, so levels 0 and 1 come straight
+    from the stage-1 / stage-2 trunk outputs through the COMPOSED weights W_s . W_lateral (112 -> 32, 224 -> 64; one
+    lsam_neck_level_fwd launch each): the 256-channel maps of those two levels -- 537 + 134 MB per 16-frame batch that
+    the reference writes only to read them back once -- are never formed.  The composition is done once, in fp32, when
+    the weights are packed.  Gradients: as in ImageEncoder.forward, only the LoRA factors (through level 2)."""
+    enc = model.image_encoder
+    if not getattr(model, "use_high_res_features_in_sam", False):
+        return enc(img_batch)
+    neck = enc.neck
+    if enc.scalp != 1 or len(neck.convs) != 4 or any(l in neck.fpn_top_down_levels for l in (0, 1)):
+        raise LsamError("forward_image: the composed high-resolution path expects the reference factory's neck "
+                        "(4 levels, scalp=1, fpn_top_down_levels=[2, 3]; sam2_model.py:18-26)")
+    dec = model.sam_mask_decoder
+    convs = (dec.conv_s0, dec.conv_s1)
+    if torch.is_grad_enabled() and any(p.requires_grad for c in convs for p in c.parameters()):
+        raise LsamError("forward_image: conv_s0 / conv_s1 must be frozen (liblsam has no weight-gradient GEMM)")
+    dt = _compute_dtype(None)
+    stages = enc.trunk(img_batch)
+    xs = neck._nhwc(stages)
+    dev = xs[0].device
+    n = len(xs) - 1
+    # levels 2 (and 3 feeding it) through the neck proper
+    pack = neck._pack_for(dt, dev)
+    sig = neck._pack_signature() + tuple((p.data_ptr(), p._version) for c in convs for p in c.parameters())
+    cache = getattr(neck, "_hr_packs", None)
+    if cache is None:
+        cache = neck._hr_packs = {}
+    hp = cache.get((dt, dev))
+    if hp is None or hp.sig != sig:
+        imgs, biases = [], []
+        for lvl, cs in enumerate(convs):
+            lat = neck.convs[n - lvl].conv
+            wl = lat.weight.detach().to(device=dev, dtype=torch.float32).reshape(lat.weight.shape[0], -1)
+            ws = cs.weight.detach().to(device=dev, dtype=torch.float32).reshape(cs.weight.shape[0], -1)
+            imgs.append(ops.neck_conv_pack((ws @ wl).contiguous(), dt))               # packing: W_s . W_lateral, once
+            biases.append((ws @ lat.bias.detach().to(dev, torch.float32) + cs.bias.detach().to(dev, torch.float32)).contiguous())
+        hp = cache[(dt, dev)] = _HighResPack(sig, imgs, biases)
+    with torch.no_grad():
+        hi = [ops.neck_level_fwd(xs[lvl], hp.imgs[lvl], hp.biases[lvl], dt, convs[lvl].out_channels) for lvl in (0, 1)]
+    low = _NeckFn.apply(neck, pack, dt, 2, *xs[2:])    # levels 2, 3 of the same neck
+    feats = [hi[0].permute(0, 3, 1, 2), hi[1].permute(0, 3, 1, 2), low[0].permute(0, 3, 1, 2)]
+    pe_as = getattr(neck.position_encoding, "forward_as", None)
+    pos = [pe_as(f) if pe_as is not None else neck.position_encoding(f).to(f.dtype) for f in feats]
+    return {"vision_features": feats[-1], "vision_pos_enc": pos, "backbone_fpn": feats}
 
 
 def build_image_encoder(hiera_kwargs: dict, d_model: int = 256, scalp: int = 1) -> ImageEncoder:

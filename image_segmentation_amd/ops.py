@@ -295,22 +295,32 @@ def lateral_conv_supported(in_channels: int, out_channels: int) -> bool:
     return lib().lsam_lateral_conv_image_bytes(in_channels, out_channels) > 0
 
 
-def lateral_conv(x2d: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor):
-    """bf16 [M, 256] = x2d (fp32 [M, K]) @ weight.T + bias in one kernel (see lsam_lateral_conv_fwd)."""
-    _need_gpu(x2d, weight, bias)
-    assert x2d.dtype == torch.float32 and x2d.is_contiguous() and x2d.dim() == 2
-    M, K = x2d.shape
-    co = weight.shape[0]
+def lateral_conv_pack(weight: torch.Tensor) -> torch.Tensor:
+    """Conv2d(K, 256, 1) weight -> LDS-resident bf16 weight image of lsam_lateral_conv_fwd (K <= 224)."""
+    _need_gpu(weight)
+    co, K = weight.shape[0], weight.shape[1]
     nbytes = lib().lsam_lateral_conv_image_bytes(K, co)
     if nbytes == 0:
         raise _C.LsamError(f"lateral conv: {K} -> {co} channels not supported")
-    img = torch.empty(nbytes, dtype=torch.uint8, device=x2d.device)
-    w = weight.detach().float().reshape(co, K).contiguous()
-    b = bias.detach().float().contiguous()
+    img = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    w = _f32c(weight.reshape(co, K))
     check(lib().lsam_lateral_conv_pack(ptr(w), K, co, ptr(img), stream()))
+    return img
+
+
+def lateral_conv_fwd(x2d: torch.Tensor, img: torch.Tensor, bias: torch.Tensor, co: int) -> torch.Tensor:
+    _need_gpu(x2d, img, bias)
+    assert x2d.dtype == torch.float32 and x2d.is_contiguous() and x2d.dim() == 2
+    M, K = x2d.shape
+    b = _f32c(bias)
     out = torch.empty(M, co, dtype=torch.bfloat16, device=x2d.device)
     check(lib().lsam_lateral_conv_fwd(ptr(x2d), ptr(img), ptr(b), ptr(out), M, K, co, stream()))
     return out
+
+
+def lateral_conv(x2d: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor):
+    """bf16 [M, 256] = x2d (fp32 [M, K]) @ weight.T + bias in one kernel (see lsam_lateral_conv_fwd)."""
+    return lateral_conv_fwd(x2d, lateral_conv_pack(weight), bias, weight.shape[0])
 
 
 def patch_embed_pack(proj_w):
@@ -374,3 +384,43 @@ def tail_block_fwd(a, res, img, vec, next_norm=None, eps: float = 1e-6, out=None
                                     ptr(xn) if xn is not None else None, d, ptr(gw) if xn is not None else None,
                                     ptr(gb) if xn is not None else None, M, d, eps, stream()))
     return (y, xn) if next_norm is not None else y
+
+
+def neck_conv_pack(weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """Conv2d(K, N, 1) weight (fp32 [N, K] or [N, K, 1, 1]) -> fragment-ordered weight image of lsam_neck_level_fwd."""
+    _need_gpu(weight)
+    co, K = weight.shape[0], weight.shape[1]
+    nbytes = lib().lsam_neck_conv_image_bytes(dtype_code(dtype), K, co)
+    if nbytes == 0:
+        raise _C.LsamError(f"neck level: {K} -> {co} channels not supported")
+    img = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    w = _f32c(weight.reshape(co, K))
+    check(lib().lsam_neck_conv_pack(dtype_code(dtype), ptr(w), K, co, ptr(img), stream()))
+    return img
+
+
+def neck_level_fwd(x_nhwc: torch.Tensor, img: torch.Tensor, bias: torch.Tensor, dtype: torch.dtype, co: int,
+                   top: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """T [N,H,W,co] = conv1x1(x) + bias (+ nearest-x2 upsample of `top` [N,H/2,W/2,co]) (see lsam_neck_level_fwd)."""
+    _need_gpu(x_nhwc, img, bias, top)
+    assert x_nhwc.dtype == torch.float32 and x_nhwc.is_contiguous() and x_nhwc.dim() == 4
+    N, H, W, K = x_nhwc.shape
+    if top is not None:
+        assert top.dtype == dtype and top.is_contiguous() and tuple(top.shape) == (N, H // 2, W // 2, co)
+    out = torch.empty(N, H, W, co, dtype=dtype, device=x_nhwc.device)
+    check(lib().lsam_neck_level_fwd(dtype_code(dtype), ptr(x_nhwc), ptr(img), ptr(bias), ptr(top), ptr(out), N, H, W, K, co,
+                                    stream()))
+    return out
+
+
+def neck_topdown_bwd(g_fine: torch.Tensor, g_coarse: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Adjoint of the nearest-x2 upsample: [N,H/2,W/2,C] = 2x2 sums of g_fine [N,H,W,C] (+ g_coarse)."""
+    _need_gpu(g_fine, g_coarse)
+    assert g_fine.is_contiguous() and g_fine.dim() == 4
+    N, H, W, Cc = g_fine.shape
+    out = torch.empty(N, H // 2, W // 2, Cc, dtype=g_fine.dtype, device=g_fine.device)
+    if g_coarse is not None:
+        assert g_coarse.dtype == g_fine.dtype and g_coarse.is_contiguous() and g_coarse.shape == out.shape
+    check(lib().lsam_neck_topdown_bwd(dtype_code(g_fine.dtype), ptr(g_fine), ptr(g_coarse), ptr(out), N, H // 2, W // 2, Cc,
+                                      stream()))
+    return out

@@ -155,6 +155,23 @@ int lsam_lateral_conv_pack(const float* weight, int in_channels, int out_channel
 int lsam_lateral_conv_fwd(const float* x, const void* image, const float* bias, void* out, int M, int in_channels,
                           int out_channels, lsam_stream_t stream);
 
+/* One FPN level in one kernel, any level and both dtypes (FpnNeck.forward, image_encoder.py:102-134):
+ *   out[n][y][x][:] = T( Conv2d(in_channels, out_channels, 1)(x)[n, :, y, x]  (+ top[n][y/2][x/2][:]) )
+ * = the lateral convolution `self.convs[n - i](x)` (:112-114) with, when top != NULL, the nearest-x2 top-down add
+ * `lateral_features + F.interpolate(prev_features.to(float32), scale_factor=2.0, mode="nearest")` (:116-125) in its
+ * epilogue.  x fp32 NHWC [N,H,W,in_channels] (a trunk stage output), top / out T NHWC ([N,H/2,W/2,out_channels] /
+ * [N,H,W,out_channels]); image from lsam_neck_conv_pack(weight fp32 [out_channels][in_channels]).
+ * out_channels in {256, 64, 32} (d_model, and the 64 / 32 outputs of mask_decoder.conv_s1 / conv_s0 composed with the
+ * lateral convolution: two 1x1 convolutions with nothing between them are one, sam2_base.py:473-478), in_channels % 8 == 0.
+ * lsam_neck_topdown_bwd is the adjoint of the upsample for the backward: out[n][y][x][:] = sum of g_fine over the 2x2
+ * children (+ g_coarse[n][y][x][:] when given), all T NHWC; the input gradient of the level is then one lsam_linear. */
+size_t lsam_neck_conv_image_bytes(int dtype, int in_channels, int out_channels);
+int lsam_neck_conv_pack(int dtype, const float* weight, int in_channels, int out_channels, void* image, lsam_stream_t stream);
+int lsam_neck_level_fwd(int dtype, const float* x, const void* image, const float* bias, const void* top, void* out, int N,
+                        int H, int W, int in_channels, int out_channels, lsam_stream_t stream);
+int lsam_neck_topdown_bwd(int dtype, const void* g_fine, const void* g_coarse, void* out, int N, int Hc, int Wc, int C,
+                          lsam_stream_t stream);
+
 /* Shortcut of a q-pool block in one kernel: out = MaxPool2d(2, 2)(A . W^T + bias) over the token grid
  * (`shortcut = do_pool(self.proj(x_norm), self.pool)`, hieradet.py:139-140; do_pool: hieradet.py:27-41).
  * A bf16 [N_img*H*W][lda] (rows = NHWC tokens), W bf16 [N][ldw], bias fp32 [N]; out fp32 [N_img*(H/2)*(W/2)][ldo].
