@@ -29,46 +29,68 @@ __global__ void pack_neck_kernel(const float* __restrict__ w, int K, int N, int 
     }
 }
 
-template <typename T, int NT, int MT>
+// NT = output column tiles per WAVE, MT = token tiles per wave, NSPLIT = 4: the four waves of a workgroup share one set of
+// 16 MT tokens and take a quarter of the output channels each (d_model = 256: every weight fragment then feeds MT MFMAs and a
+// wave holds only MT x NT accumulators, which leaves registers for a one-k-step-ahead prefetch of both operands; the three
+// other waves' re-reads of x hit L1); NSPLIT = 1: every wave has its own tokens and all output channels (32 / 64 channels).
+template <typename T, int NT, int MT, int NSPLIT>
 __global__ __launch_bounds__(256) void neck_level_kernel(const float* __restrict__ x, const T* __restrict__ wimg,
                                                          const float* __restrict__ bias, const T* __restrict__ top,
                                                          T* __restrict__ out, int M, int K, int H, int W) {
     using frag = typename Tr<T>::frag;
-    constexpr int N = 16 * NT;
+    constexpr int NTA = NT * NSPLIT, N = 16 * NTA;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, lr = lane & 15;
-    const int m0 = (blockIdx.x * 4 + wave) * 16 * MT;
+    const int m0 = (NSPLIT == 1 ? blockIdx.x * 4 + wave : blockIdx.x) * 16 * MT;
+    const int nt0 = NSPLIT == 1 ? 0 : wave * NT;
     if (m0 >= M) return;   // wave-uniform; the kernel has no barrier
     const int nks = (K + 31) / 32;
 
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const f32x4 b = load4(bias + 16 * nt + 4 * g);
+        const f32x4 b = load4(bias + 16 * (nt0 + nt) + 4 * g);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = b;
     }
     const float* rows[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) rows[mt] = x + (size_t)min(m0 + 16 * mt + lr, M - 1) * K;   // clamped rows are never stored
-    const frag* wf = reinterpret_cast<const frag*>(wimg) + lane;
+    const frag* wf = reinterpret_cast<const frag*>(wimg) + (size_t)nt0 * 64 + lane;
 
-    for (int ks = 0; ks < nks; ++ks) {
+    auto load_x = [&](int ks, f32x4 (&xa)[MT], f32x4 (&xb)[MT]) {
         const int c0 = 32 * ks + 8 * g;
-        frag xf[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
-            if (c0 < K) { a = load4(rows[mt] + c0); b = load4(rows[mt] + c0 + 4); }
+            xa[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            xb[mt] = xa[mt];
+            if (c0 < K) { xa[mt] = load4(rows[mt] + c0); xb[mt] = load4(rows[mt] + c0 + 4); }
+        }
+    };
+    auto load_w = [&](int ks, frag (&w)[NT]) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { xf[mt][j] = from_f<T>(a[j]); xf[mt][4 + j] = from_f<T>(b[j]); }
+        for (int nt = 0; nt < NT; ++nt) w[nt] = wf[(size_t)(ks * NTA + nt) * 64];
+    };
+    f32x4 xa[MT], xb[MT];
+    frag w[NT];
+    load_x(0, xa, xb);
+    load_w(0, w);
+    for (int ks = 0; ks < nks; ++ks) {
+        frag xf[MT], wc[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { xf[mt][j] = from_f<T>(xa[mt][j]); xf[mt][4 + j] = from_f<T>(xb[mt][j]); }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wc[nt] = w[nt];
+        if (ks + 1 < nks) {   // the next k-step's operands are in flight under this one's MFMAs
+            load_x(ks + 1, xa, xb);
+            load_w(ks + 1, w);
         }
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const frag w = wf[(size_t)(ks * NT + nt) * 64];
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) mma16(w, xf[mt], acc[mt][nt]);
-        }
+            for (int mt = 0; mt < MT; ++mt) mma16(wc[nt], xf[mt], acc[mt][nt]);
     }
 
 #pragma unroll
@@ -76,11 +98,11 @@ __global__ __launch_bounds__(256) void neck_level_kernel(const float* __restrict
         const int m = m0 + 16 * mt + lr;
         const bool ok = m < M;
         const int mc = ok ? m : M - 1;
-        T* rowp = out + (size_t)mc * N;
+        T* rowp = out + (size_t)mc * N + 16 * nt0;
         const T* trow = nullptr;
         if (top) {   // nearest x2: token (n, y, xx) of the H x W grid takes the coarse token (n, y / 2, xx / 2)
             const int xx = mc % W, y = (mc / W) % H, n = mc / (W * H);
-            trow = top + ((size_t)(n * (H / 2) + y / 2) * (W / 2) + xx / 2) * N;
+            trow = top + ((size_t)(n * (H / 2) + y / 2) * (W / 2) + xx / 2) * N + 16 * nt0;
         }
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -157,15 +179,20 @@ int launch_neck_level(const float* x, const void* img, const float* bias, const 
     const T* wi = static_cast<const T*>(img);
     const T* tp = static_cast<const T*>(top);
     T* o = static_cast<T*>(out);
-#define NECK_LAUNCH(NT, MT)                                                                                              \
-    hipLaunchKernelGGL((neck_level_kernel<T, NT, MT>), dim3(cdiv(M, 64 * MT)), dim3(256), 0, s, x, wi, bias, tp, o, M, K, H, W)
+#define NECK_LAUNCH(NT, MT, NSPLIT)                                                                                      \
+    hipLaunchKernelGGL((neck_level_kernel<T, NT, MT, NSPLIT>), dim3(cdiv(M, (NSPLIT == 1 ? 64 : 16) * MT)), dim3(256), 0, s, x, \
+                       wi, bias, tp, o, M, K, H, W)
     if (v == 0) {
-        if constexpr (sizeof(T) == 2) NECK_LAUNCH(16, 2);
-        else NECK_LAUNCH(16, 1);
+        if constexpr (sizeof(T) == 2) {
+            if (M >= 32768) NECK_LAUNCH(4, 4, 4);   // 64 tokens per workgroup
+            else NECK_LAUNCH(4, 2, 4);              // small levels: 32 tokens, twice the workgroups
+        } else {
+            NECK_LAUNCH(4, 2, 4);
+        }
     } else if (v == 1) {
-        NECK_LAUNCH(4, 4);
+        NECK_LAUNCH(4, 4, 1);
     } else {
-        NECK_LAUNCH(2, 4);
+        NECK_LAUNCH(2, 4, 1);
     }
 #undef NECK_LAUNCH
     LSAM_LAUNCH_CHECK();

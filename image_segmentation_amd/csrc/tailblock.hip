@@ -928,6 +928,8 @@ int launch_tailblock(const TailBlockArgs& a, hipStream_t s) {
         case 0: return launch_tail<7, 14, 4, 4, 1>(a, s);
 #elif defined(TAIL_224_MT2)
         case 0: return launch_tail<7, 14, 2, 4, 2>(a, s);
+#elif defined(TAIL_224_MT2W8)
+        case 0: return launch_tail<7, 14, 2, 8, 2>(a, s);   // 8 waves x 32 tokens: half the chunk traffic and barriers per token
 #else
         case 0: return launch_tail<7, 14, 1, 8, 2>(a, s);    // 8 waves x 16 tokens: fits 2 waves per SIMD
 #endif
