@@ -593,8 +593,11 @@ template <int OFF, typename V> __device__ __forceinline__ void g3_rd(unsigned ad
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 }
 
-template <bool OUTF32, bool POOL>
+// NGUARD: N need not be a multiple of 224 (Hiera-L widths, multiples of 144): W rows >= N are zero-filled by the DMA's
+// range check and every epilogue access is guarded by its column.
+template <bool OUTF32, bool POOL, bool NGUARD = false>
 __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
+    static_assert(!(POOL && NGUARD), "pooled epilogue needs N % 224 == 0");
     using T = bf16;
     constexpr int MT = 4, NT = 7, BM = 256, BN = 224, NW = 8, BK = 64, A_IT = 4;
     constexpr int STAGE = 65536;       // 512 rows x 128 B; rows 480..511 only take the padding DMA pieces
@@ -608,7 +611,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
     const int wm = wave & 3, wn = wave >> 2;
     const int g = lane >> 4, lr = lane & 15;
     const int M = p.M, N = p.N, K = p.K;
-    const int tiles_n = N / BN, tiles_m = (M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
+    const int tiles_n = NGUARD ? (N + BN - 1) / BN : N / BN, tiles_m = (M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
     const int G = gridDim.x;
     const int slot = xcd_remap(blockIdx.x, G);
     if (slot >= ntiles) return;
@@ -669,11 +672,11 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const unsigned vo = kok ? ta.woff0 + i * wstep + kb : 0xFFFFFFFFu;   // N % 224 == 0: every W row exists
+            const unsigned vo = (kok && (!NGUARD || ta.wrow0 + 64 * i < N)) ? ta.woff0 + i * wstep + kb : 0xFFFFFFFFu;   // N % 224 == 0: every W row exists
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(base + (32 + wave + NW * i) * 1024), 16, vo, 0, 0, 0);
         }
         if (wave < 4) {
-            const unsigned vo = kok ? ta.woff0 + 3 * wstep + kb : 0xFFFFFFFFu;
+            const unsigned vo = (kok && (!NGUARD || ta.wrow0 + 192 < N)) ? ta.woff0 + 3 * wstep + kb : 0xFFFFFFFFu;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(base + (32 + wave + NW * 3) * 1024), 16, vo, 0, 0, 0);
         } else if (wave == 4 && kt == 0) {
             const unsigned vo = lane < 56 ? (unsigned)(ta.n0 + 4 * lane) * 4u : 0xFFFFFFFFu;
@@ -697,11 +700,11 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_ptr_t)(base + (wave + NW * idx) * 1024), 16, vo, 0, 0, 0);
         } else if constexpr (idx < A_IT + 3) {
             constexpr int i = idx - A_IT;
-            const unsigned vo = kok ? ta.woff0 + i * wstep + kb : 0xFFFFFFFFu;
+            const unsigned vo = (kok && (!NGUARD || ta.wrow0 + 64 * i < N)) ? ta.woff0 + i * wstep + kb : 0xFFFFFFFFu;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(base + (32 + wave + NW * i) * 1024), 16, vo, 0, 0, 0);
         } else {
             if (wave < 4) {
-                const unsigned vo = kok ? ta.woff0 + 3 * wstep + kb : 0xFFFFFFFFu;
+                const unsigned vo = (kok && (!NGUARD || ta.wrow0 + 192 < N)) ? ta.woff0 + 3 * wstep + kb : 0xFFFFFFFFu;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(base + (32 + wave + NW * 3) * 1024), 16, vo, 0, 0, 0);
             } else if (wave == 4 && kt == 0) {
                 const unsigned vo = lane < 56 ? (unsigned)(ta.n0 + 4 * lane) * 4u : 0xFFFFFFFFu;
@@ -751,19 +754,25 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
             const int m = m0 + wm * 64 + mt * 16 + lr;
             const bool mok = m < M;
             const int mc = mok ? m : M - 1;
+            // NGUARD: column c of this wave's 112 is inside the matrix while c < nlim (N % 8 == 0: a 16- or 8-byte store
+            // is inside or outside as a whole)
+            const int nlim = NGUARD ? N - (n0 + wn * 112) : 112;
             auto store_row = [&](auto* base, int ld, const f32x4 (&val)[NT]) {
                 auto* rowp = base + (size_t)mc * ld + n0 + wn * 112;
                 if constexpr (sizeof(*base) == 4) {
                     if (mok) {
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) store4(rowp + nt * 16 + 4 * g, val[nt]);
+                        for (int nt = 0; nt < NT; ++nt)
+                            if (!NGUARD || nt * 16 + 4 * g < nlim) store4(rowp + nt * 16 + 4 * g, val[nt]);
                     }
                 } else {
 #pragma unroll
-                    for (int nt = 0; nt + 1 < NT; nt += 2) store_bf16_tile_pair(rowp + nt * 16, g, val[nt], val[nt + 1], mok);
-                    if (mok) store4(rowp + (NT - 1) * 16 + 4 * g, val[NT - 1]);
+                    for (int nt = 0; nt + 1 < NT; nt += 2)
+                        store_bf16_tile_pair(rowp + nt * 16, g, val[nt], val[nt + 1], mok && (!NGUARD || nt * 16 + 8 * g < nlim));
+                    if (mok && (!NGUARD || (NT - 1) * 16 + 4 * g < nlim)) store4(rowp + (NT - 1) * 16 + 4 * g, val[NT - 1]);
                 }
             };
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
             f32x4 v[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) v[nt] = acc[mt][nt];
@@ -778,7 +787,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
                 const T* xp = static_cast<const T*>(p.aux) + (size_t)mc * p.ldaux + nc;
                 f32x4 x[NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) x[nt] = load4(xp + 16 * nt);
+                for (int nt = 0; nt < NT; ++nt) x[nt] = (!NGUARD || nt * 16 + 4 * g < nlim) ? load4(xp + 16 * nt) : z4;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -788,7 +797,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
                 const float* rp = p.res + (p.res_row_mod > 0 ? (size_t)(mc % p.res_row_mod) : (size_t)mc) * p.ldres + nc;
                 f32x4 rv[NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) rv[nt] = load4(rp + 16 * nt);
+                for (int nt = 0; nt < NT; ++nt) rv[nt] = (!NGUARD || nt * 16 + 4 * g < nlim) ? load4(rp + 16 * nt) : z4;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) v[nt] += rv[nt];
             }
@@ -938,7 +947,8 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
             after = 12;   // 14 stores; counted a little short so that a store the compiler fuses or drops cannot matter
         } else {
             epilogue(m0, n0);
-            after = m0 + BM <= M ? (OUTF32 ? 24 : 12) : 0;   // full tile: 28 (fp32) / 16 (bf16) stores, counted short
+            // full tile: 28 (fp32) / 16 (bf16) stores, counted short; a partial tile issues fewer: wait for everything
+            after = (m0 + BM <= M && (!NGUARD || n0 + BN <= N)) ? (OUTF32 ? 24 : 12) : 0;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1048,20 +1058,20 @@ template <typename T, int WN, bool OUTF32, bool POOL = false> static int launch_
     return LSAM_OK;
 }
 
-template <bool OUTF32, bool POOL = false> static int launch_v3(const GemmArgs& a, hipStream_t s) {
+template <bool OUTF32, bool POOL = false, bool NGUARD = false> static int launch_v3(const GemmArgs& a, hipStream_t s) {
     constexpr int LDS = 2 * 65536 + 4096;
-    auto kern = gemm3_kernel<OUTF32, POOL>;
+    auto kern = gemm3_kernel<OUTF32, POOL, NGUARD>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         LSAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
-    const int ntiles = cdiv(a.M, 256) * (a.N / 224);
+    const int ntiles = cdiv(a.M, 256) * cdiv(a.N, 224);
     const int nblk = ntiles < 256 ? ntiles : 256;   // persistent: one workgroup per CU
     const int rec = prof_begin(s);
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), LDS, s, a);
     LSAM_LAUNCH_CHECK();
-    prof_end(rec, s, 2.0 * a.M * a.N * a.K, 2000 + 224 + (OUTF32 ? 1 : 0), a.M, a.N, a.K);
+    prof_end(rec, s, 2.0 * a.M * a.N * a.K, 2000 + 224 + (OUTF32 ? 1 : 0) + (NGUARD ? 2 : 0), a.M, a.N, a.K);
     return LSAM_OK;
 }
 
@@ -1100,6 +1110,17 @@ template <typename T> int launch_gemm(const GemmArgs& a, hipStream_t s) {
         } else {
             set_error("linear: pooled epilogue is bf16 only");
             return LSAM_ERR_UNSUPPORTED;
+        }
+    }
+    if constexpr (sizeof(T) == 2) {
+        // widths that are not multiples of 112 (Hiera-T/S/L: multiples of 96 / 144): the 256 x 224 kernel with column guards
+        // once a tile row is reasonably full
+        if (GEMM3 && a.N % 112 != 0 && a.N >= 144 && a.M >= 1024 &&
+            (double)a.M * a.lda * sizeof(T) < 2.0e9 && (double)a.N * a.ldw * sizeof(T) < 2.0e9 && a.ldo % 8 == 0 &&
+            (!(a.flags & LSAM_EPI_SAVE_PRE) || (a.ldo2 % 8 == 0 && aligned16(a.out2))) &&
+            (!(a.flags & LSAM_EPI_GELU_BWD) || a.ldaux % 4 == 0) && (!a.res || a.ldres % 4 == 0)) {
+            const bool of32 = (a.flags & LSAM_EPI_OUT_F32) != 0;
+            return of32 ? launch_v3<true, false, true>(a, s) : launch_v3<false, false, true>(a, s);
         }
     }
     if (a.N % 112 == 0 && (double)a.M * a.lda * sizeof(T) < 2.0e9 && (double)a.N * a.ldw * sizeof(T) < 2.0e9 && a.M >= 1024 &&

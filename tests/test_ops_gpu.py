@@ -66,6 +66,33 @@ def test_linear_persistent_many_tiles(ops, M, N, K):
     assert rel_err(pre.double(), ref) < 5e-3 and rel_err(out.double(), F.gelu(ref)) < 5e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(33000, 432, 144), (20000, 576, 144), (5000, 288, 288), (70000, 144, 576), (9000, 1152, 288),
+                                   (1100, 3456, 1184), (2000, 152, 64), (40000, 864, 320), (1500, 96 * 3, 96)])
+def test_linear_column_guarded_tiles(ops, M, N, K):
+    """bf16, N NOT a multiple of 224 (Hiera-L widths are multiples of 144, Hiera-T/S of 96): the 256 x 224 persistent kernel
+    with zero-filled weight rows and column-guarded epilogues -- every epilogue flavour, ragged M, K tails, and a poisoned
+    output buffer to show that nothing is written past column N."""
+    dt = torch.bfloat16
+    A, W = rnd(M, K, seed=1).cuda().to(dt), (rnd(N, K, seed=2) / math.sqrt(K)).cuda().to(dt)
+    b, res = rnd(N, seed=3).cuda(), rnd(M, N, seed=4).cuda()
+    ref = A.double() @ W.double().t() + b.double()
+    wide = torch.full((M, N + 40), 7.0, device="cuda")
+    ops.linear(A, W, b, res=res, out_f32=True, out=wide[:, :N])
+    assert rel_err(wide[:, :N].double(), ref + res.double()) < 1e-6
+    assert bool((wide[:, N:] == 7.0).all())
+    wide16 = torch.full((M, N + 40), 7.0, device="cuda", dtype=dt)
+    ops.linear(A, W, b, out=wide16[:, :N])
+    assert rel_err(wide16[:, :N].double(), ref) < 5e-3
+    assert bool((wide16[:, N:] == 7.0).all())
+    out, pre = ops.linear(A, W, b, gelu=True, save_pre=True)
+    assert rel_err(pre.double(), ref) < 5e-3 and rel_err(out.double(), F.gelu(ref)) < 5e-3
+    aux = rnd(M, N, seed=6).cuda().to(dt)
+    out = ops.linear(A, W, None, gelu_bwd_aux=aux, out_f32=True)
+    x = aux.float().cpu().double().requires_grad_(True)
+    F.gelu(x).sum().backward()
+    assert rel_err(out, (ref.cpu() - b.cpu().double()) * x.grad) < 2e-5
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M", [192, 1216])
 def test_linear_epilogues(ops, dt, M):

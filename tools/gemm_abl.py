@@ -9,7 +9,10 @@ if os.environ.get("LSAM_LIB"):
 from image_segmentation_amd import ops
 dev = torch.device("cuda", 0)
 shapes = [(65536, 448, 448), (65536, 1344, 448), (65536, 1792, 448), (65536, 448, 1792),
-          (16384, 896, 3584), (16384, 3584, 896), (262144, 224, 224), (262144, 896, 224), (262144, 224, 896)]
+          (16384, 896, 3584), (16384, 3584, 896), (262144, 224, 224), (262144, 896, 224), (262144, 224, 896),
+          (16384, 896, 896), (16384, 2688, 928), (16384, 896, 2720), (16384, 896, 256), (262144, 672, 224), (262144, 448, 224)]
+if os.environ.get("GEMM_SHAPES"):
+    shapes = [tuple(int(v) for v in s.split("x")) for s in os.environ["GEMM_SHAPES"].split(",")]
 print(os.environ.get("LSAM_LIB", "liblsam.so"))
 for (M, N, K) in shapes:
     A = torch.randn(M, K, device=dev).bfloat16()
