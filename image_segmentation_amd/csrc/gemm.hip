@@ -1099,6 +1099,28 @@ template <typename T> int launch_gemm(const GemmArgs& a, hipStream_t s) {
                  "linear: GELU_BWD needs aux");
     LSAM_REQUIRE(!(a.flags & LSAM_EPI_SAVE_PRE) || (a.out2 && a.ldo2 % 4 == 0), LSAM_ERR_BAD_ARG,
                  "linear: SAVE_PRE needs out2");
+    // The LDS-DMA kernels address A with 32-bit buffer offsets: an operand of 2 GB or more (Hiera-L at 64 frames: 4.2 M
+    // tokens x 576 channels) is cut into row slices, one launch each, instead of falling back to the slow generic kernel.
+    if (a.pool_w == 0 && a.res_row_mod == 0 && a.M >= 2048 && (double)a.M * a.lda * sizeof(T) >= 2.0e9 &&
+        (double)a.N * a.ldw * sizeof(T) < 2.0e9) {
+        long rows = (long)(1.9e9 / ((double)a.lda * sizeof(T)));
+        rows -= rows % 256;
+        if (rows >= 1024) {
+            const bool of32 = (a.flags & LSAM_EPI_OUT_F32) || sizeof(T) == 4;
+            for (long m0 = 0; m0 < a.M; m0 += rows) {
+                GemmArgs b = a;
+                b.M = (int)((a.M - m0) < rows ? (a.M - m0) : rows);
+                b.A = static_cast<const T*>(a.A) + (size_t)m0 * a.lda;
+                if (a.res) b.res = a.res + (size_t)m0 * a.ldres;
+                if (a.aux) b.aux = static_cast<const T*>(a.aux) + (size_t)m0 * a.ldaux;
+                if (a.out2) b.out2 = static_cast<T*>(a.out2) + (size_t)m0 * a.ldo2;
+                b.out = of32 ? static_cast<void*>(static_cast<float*>(a.out) + (size_t)m0 * a.ldo)
+                             : static_cast<void*>(static_cast<T*>(a.out) + (size_t)m0 * a.ldo);
+                LSAM_TRY(launch_gemm<T>(b, s));
+            }
+            return LSAM_OK;
+        }
+    }
     if (a.pool_w > 0) {
         if constexpr (sizeof(T) == 2) {
             LSAM_REQUIRE(gemm_pool_supported(a.pool_h, a.pool_w, a.N) && a.M % (a.pool_h * a.pool_w) == 0 &&

@@ -93,6 +93,28 @@ def test_linear_column_guarded_tiles(ops, M, N, K):
     assert rel_err(out, (ref.cpu() - b.cpu().double()) * x.grad) < 2e-5
 
 
+def test_linear_operand_over_2GB_is_row_sliced(ops):
+    """An A operand of 2 GB or more (Hiera-L at 64 frames) exceeds the 32-bit buffer offsets of the LDS-DMA kernels: the
+    launcher cuts it into row slices.  Checked on row samples from the first slice, the seam and the ragged end."""
+    dt = torch.bfloat16
+    M, N, K = 1_100_037, 224, 1024                     # A: 2.25 GB
+    g = torch.Generator(device="cuda").manual_seed(5)
+    A = torch.randn(M, K, device="cuda", generator=g, dtype=torch.float32).to(dt)
+    W = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(dt)
+    b = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(M, N, device="cuda", generator=g)
+    out = ops.linear(A, W, b, res=res, out_f32=True)
+    seam = int(1.9e9 / (K * 2)) // 256 * 256
+    for lo in (0, seam - 500, M - 700):
+        sl = slice(lo, lo + 700)
+        ref = A[sl].double() @ W.double().t() + b.double() + res[sl].double()
+        assert rel_err(out[sl].double(), ref) < 1e-6, lo
+    out16, pre = ops.linear(A, W, b, gelu=True, save_pre=True)
+    sl = slice(seam - 300, seam + 300)
+    ref = A[sl].double() @ W.double().t() + b.double()
+    assert rel_err(pre[sl].double(), ref) < 5e-3 and rel_err(out16[sl].double(), F.gelu(ref)) < 5e-3
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M", [192, 1216])
 def test_linear_epilogues(ops, dt, M):
