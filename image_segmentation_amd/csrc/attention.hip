@@ -383,10 +383,16 @@ __device__ uint4 g_attn_one16 = {0x00003F80u, 0u, 0u, 0u};   // bf16 1.0 followe
 #ifndef ATTN2_QT
 #define ATTN2_QT 4
 #endif
-template <int QT, bool ONES>
-__global__ __launch_bounds__(256, QT == 2 ? 3 : 2) void attn2_fwd_kernel(const AttnArgs p, const float c_log2) {
+// KSQ = 32-wide k-steps of Q K^T, DT = 16-wide output tiles: (2, 4) for head_dim <= 64 (128-byte tile rows);
+// (3, 5) / (3, 6) for head_dim <= 80 / 96 (Hiera-L: 72, Hiera-T/S: 96) on 256-byte tile rows of 16 chunks.
+template <int QT, bool ONES, int KSQ = 2, int DT = 4>
+__global__ __launch_bounds__(256, (QT == 2 && KSQ == 2) ? 3 : 2) void attn2_fwd_kernel(const AttnArgs p, const float c_log2) {
     using T = bf16;
-    constexpr int KT2 = 64, RB = 128, TILE_B = KT2 * RB, STAGE = 2 * TILE_B, DT = 4;
+    static_assert((KSQ == 2 && DT == 4) || (KSQ == 3 && (DT == 5 || DT == 6)), "supported head_dim classes");
+    constexpr int KT2 = 64, RB = KSQ == 2 ? 128 : 256, TILE_B = KT2 * RB, STAGE = 2 * TILE_B;
+    constexpr int CPR = RB / 16, SWM = CPR - 1;      // chunks per row; the swizzle XORs the chunk index with row & SWM
+    constexpr int RPI = 1024 / RB, NE = KT2 / RPI / 4;   // tile rows per DMA wave-instruction; instructions per wave and operand
+    auto swzk = [](int row, int chunk) { return chunk ^ (row & SWM); };
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(256, QT == 2 ? 3 : 2) void attn2_fwd_kernel(const A
     const size_t img_tok = (size_t)n * H * W;
 
     // ---- Q fragments ----------------------------------------------------------------------------
-    bf16x8 qf[QT][2];
+    bf16x8 qf[QT][KSQ];
     int qtok[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(256, QT == 2 ? 3 : 2) void attn2_fwd_kernel(const A
         const int iy = qv ? qi / rw : 0, ix = qv ? qi % rw : 0;
         qtok[qt] = qv ? (int)(((size_t)n * G.Ho + (wy * G.qh + iy)) * G.Wo + (wx * G.qw + ix)) : -1;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KSQ; ++ks) {
             const int d0 = ks * 32 + g * 8;
             float v[8];
 #pragma unroll
@@ -456,19 +462,20 @@ __global__ __launch_bounds__(256, QT == 2 ? 3 : 2) void attn2_fwd_kernel(const A
     // ---- DMA lane mapping: instruction j = wave + 4 i covers rows 8(j&7).. of K (j<8) or V (j>=8);
     // a lane therefore touches two keys per tile (tile rows r0 and r0 + 32), whose window
     // coordinates are advanced incrementally from tile to tile (no per-tile division).
-    const int lrow = lane >> 3, dsrc = ((lane & 7) ^ lrow) * 8;   // source d offset of this lane's chunk
+    // (tile row of instruction j = wave + 4 e: RPI j + lrow; its low swizzle bits do not depend on e)
+    const int lrow = lane / CPR, dsrc = ((lane % CPR) ^ ((RPI * wave + lrow) & SWM)) * 8;   // source d offset of this lane's chunk
     const bool dok = dsrc < hd;
     const int kstep_y = KT2 / G.wsw, kstep_x = KT2 % G.wsw;
-    int kky[2], kkx[2];
+    int kky[NE], kkx[NE];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int kk = 8 * wave + lrow + 32 * e;
+    for (int e = 0; e < NE; ++e) {
+        const int kk = RPI * wave + lrow + 4 * RPI * e;
         kky[e] = kk / G.wsw;
         kkx[e] = kk - kky[e] * G.wsw;
     }
     auto issue = [&](int buf) {   // stages the tile the (kky, kkx) cursors point at, then advances them
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < NE; ++e) {
             const int y = wy * G.wsh + kky[e], x = wx * G.wsw + kkx[e];
             const bool kin = kky[e] < G.wsh && dok;            // key index < nk
             const bool real = y < H && x < W;
@@ -479,8 +486,7 @@ __global__ __launch_bounds__(256, QT == 2 ? 3 : 2) void attn2_fwd_kernel(const A
                 const void* src = &g_attn_zero16;
                 if (kin) src = real ? static_cast<const void*>(qkv + tokoff + part) : static_cast<const void*>(bias_t + part);
                 if (ONES && v == 1 && dsrc == hd && kky[e] < G.wsh) src = &g_attn_one16;
-                const int j = wave + 4 * e + 8 * v;
-                __builtin_amdgcn_global_load_lds((gbl_vp_t)src, (lds_vp_t)(smem + buf * STAGE + j * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_vp_t)src, (lds_vp_t)(smem + buf * STAGE + v * TILE_B + (wave + 4 * e) * 1024), 16, 0, 0);
             }
             kky[e] += kstep_y;
             kkx[e] += kstep_x;
@@ -514,13 +520,13 @@ __global__ __launch_bounds__(256, QT == 2 ? 3 : 2) void attn2_fwd_kernel(const A
         const unsigned vb_lds = lds0 + buf * STAGE + TILE_B;
         const bool tail = __builtin_amdgcn_readfirstlane(tile * KT2 + KT2 > nk ? 1 : 0) != 0;
 
-        bf16x8 kf[4][2];
+        bf16x8 kf[4][KSQ];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < KSQ; ++ks) {
                 const int row = t * 16 + lr;
-                kf[t][ks] = *reinterpret_cast<const bf16x8*>(kb + row * RB + (swz(row, ks * 4 + g) << 4));
+                kf[t][ks] = *reinterpret_cast<const bf16x8*>(kb + row * RB + (swzk(row, ks * 4 + g) << 4));
             }
         bf16x8 pf[QT][2];
 #pragma unroll
@@ -529,7 +535,8 @@ __global__ __launch_bounds__(256, QT == 2 ? 3 : 2) void attn2_fwd_kernel(const A
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][0], qf[qt][0], negm[qt], 0, 0, 0);
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][1], qf[qt][1], s[t], 0, 0, 0);
+#pragma unroll
+                for (int ks = 1; ks < KSQ; ++ks) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][ks], qf[qt][ks], s[t], 0, 0, 0);
             }
             // online softmax on s - m; O (and l) are rescaled only when some row's maximum actually moved
             // (exact, not a threshold)
@@ -584,9 +591,9 @@ __global__ __launch_bounds__(256, QT == 2 ? 3 : 2) void attn2_fwd_kernel(const A
 #define LSAM_VREAD(dst, u)                                                                              \
     _Pragma("unroll") for (int dt = 0; dt < DT; ++dt) {                                                 \
         const int row = 32 * (u) + 4 * g + (lr >> 2), ch = 2 * dt + ((lr & 3) >> 1);                    \
-        const unsigned a0 = vb_lds + row * RB + (swz(row, ch) << 4) + (lr & 1) * 8;                     \
+        const unsigned a0 = vb_lds + row * RB + (swzk(row, ch) << 4) + (lr & 1) * 8;                    \
         const int row1 = row + 16;                                                                      \
-        const unsigned a1 = vb_lds + row1 * RB + (swz(row1, ch) << 4) + (lr & 1) * 8;                   \
+        const unsigned a1 = vb_lds + row1 * RB + (swzk(row1, ch) << 4) + (lr & 1) * 8;                  \
         asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst[dt][0]) : "v"(a0));                         \
         asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst[dt][1]) : "v"(a1));                         \
     }
@@ -850,6 +857,17 @@ static int attnw_launch(const AttnArgs& a, hipStream_t s) {
     return LSAM_OK;
 }
 
+// head_dim 65..96 (Hiera-L 72, Hiera-T/S 96): the same streaming kernel on 256-byte tile rows, two query tiles per wave
+static int attn2_wide_launch(const AttnArgs& a, int max_nq, hipStream_t s) {
+    const WinGeom G = make_geom(a.H, a.W, a.ws, a.pool);
+    const float c = (1.0f / sqrtf((float)a.hd)) * 1.4426950408889634f;
+    const dim3 grid(a.N * G.nwy * G.nwx, a.nh, cdiv(max_nq, 128)), blk(256);
+    if (a.hd <= 80) hipLaunchKernelGGL((attn2_fwd_kernel<2, false, 3, 5>), grid, blk, 0, s, a, c);
+    else hipLaunchKernelGGL((attn2_fwd_kernel<2, false, 3, 6>), grid, blk, 0, s, a, c);
+    LSAM_LAUNCH_CHECK();
+    return LSAM_OK;
+}
+
 template <int QT> static int attn2_launch(const AttnArgs& a, int nqb, hipStream_t s) {
     const WinGeom G = make_geom(a.H, a.W, a.ws, a.pool);
     const float c = (1.0f / sqrtf((float)a.hd)) * 1.4426950408889634f;
@@ -901,6 +919,10 @@ template <typename T> int launch_attn_fwd(const AttnArgs& a, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         if (a.bias_t && a.hd <= 64 && a.ws > 0 && G.wsh * G.wsw > 64 && G.wsh * G.wsw <= 208 && max_nq > 64 && a.ldqkv % 8 == 0)
             return attnw_launch(a, s);   // (pooled windows have few queries per staged K/V tile: the streaming kernel below)
+        // (not for a forward that feeds the backward: this kernel rounds the PRE-SCALED queries to bf16, so its log-sum-exp
+        // belongs to slightly different scores than the ones lsam_attention_bwd recomputes -- 13 % error in dA_q measured)
+        if (a.bias_t && !a.lse && a.hd > 64 && a.hd <= 96 && G.wsh * G.wsw >= 64 && max_nq >= 32 && a.ldqkv % 8 == 0)
+            return attn2_wide_launch(a, max_nq, s);
         if (a.bias_t && a.hd <= 64 && G.wsh * G.wsw >= 128 && max_nq >= 32 && a.ldqkv % 8 == 0) {
             if (max_nq > 64) return attn2_launch<ATTN2_QT>(a, cdiv(max_nq, 64 * ATTN2_QT), s);
             return attn2_launch<1>(a, 1, s);

@@ -224,16 +224,21 @@ def test_attention_fwd(ops, dt, H, ws, pool, nh):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("H,ws,pool,nh", [(16, 8, 1, 2), (16, 8, 2, 2), (32, 16, 1, 4), (32, 16, 2, 2), (16, 0, 1, 2)])
-def test_attention_fwd_head_dim_72(ops, dt, H, ws, pool, nh):
-    """Hiera-L heads (head_dim 72, windows 8/16, global): the 128-wide LDS-row build of the kernel."""
-    N, hd = 2, 72
+@pytest.mark.parametrize("hd", [72, 96])
+@pytest.mark.parametrize("H,ws,pool,nh", [(16, 8, 1, 2), (16, 8, 2, 2), (32, 16, 1, 4), (32, 16, 2, 2), (16, 0, 1, 2), (64, 0, 1, 1),
+                                          (40, 16, 1, 2), (28, 14, 1, 2), (28, 14, 2, 2)])
+def test_attention_fwd_head_dim_72(ops, dt, H, ws, pool, nh, hd):
+    """Hiera-L heads (head_dim 72, windows 8/16, global) and Hiera-T/S heads (96): the streaming LDS-DMA kernel on
+    256-byte tile rows (bf16, >= 64 keys and >= 32 queries per window) and the generic kernel otherwise."""
+    N = 2
     qkv = rnd(N, H, H, 3 * nh * hd, seed=H + ws + 1).cuda().to(dt)
     bias = rnd(3 * nh * hd, seed=10) * 0.5
     out, lse = ops.attention_fwd(qkv, bias.cuda(), ws, pool, nh, want_lse=True)
     ref, lse_ref = ref_attention(qkv.float().cpu(), bias.cuda().to(dt).float().cpu(), H, H, ws, pool, nh)
     assert rel_err(out.float(), ref) < tol(dt, 3e-6, 6e-3)
     assert rel_err(lse, lse_ref) < tol(dt, 1e-5, 2e-3)
+    out = ops.attention_fwd(qkv, bias.cuda(), ws, pool, nh)      # inference form (no log-sum-exp): the LDS-DMA kernel in bf16
+    assert rel_err(out.float(), ref) < tol(dt, 3e-6, 6e-3)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
