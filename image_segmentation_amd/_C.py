@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblsam.so")
 
 F32, BF16 = 0, 1
-EPI_GELU, EPI_GELU_BWD, EPI_OUT_F32, EPI_SAVE_PRE = 1, 2, 4, 8
+EPI_GELU, EPI_GELU_BWD, EPI_OUT_F32, EPI_SAVE_PRE, EPI_RELU, EPI_SIGMOID = 1, 2, 4, 8, 16, 32
 
 
 class LsamError(RuntimeError):
@@ -98,6 +98,12 @@ def lib() -> C.CDLL:
                      "lsam_mlp_block_image_bytes", "lsam_mlp_block_bias_floats",
                      "lsam_tail_block_image_bytes", "lsam_tail_block_vec_floats", "lsam_patch_embed_image_bytes"):
             getattr(L, name).argtypes = [i]
+        L.lsam_add_rows.argtypes = [i, vp, i, vp, i, i, i, vp, i, i, i, vp]
+        L.lsam_mha_fwd.argtypes = [i, vp, i, l, vp, i, l, vp, i, l, vp, i, l, i, i, i, i, i, vp]
+        L.lsam_pe_encode.argtypes = [vp, vp, vp, i, i, vp]
+        L.lsam_upscale2x2_fwd.argtypes = [i, vp, vp, vp, vp, f, vp, i, i, i, i, vp]
+        L.lsam_mask_gate.argtypes = [vp, i, vp, vp, i, i, i, i, f, vp]
+        L.lsam_bilinear_upsample.argtypes = [vp, vp, i, i, i, i, vp]
         L.lsam_lateral_conv_image_bytes.argtypes = [i, i]
         L.lsam_neck_conv_image_bytes.restype = C.c_size_t
         L.lsam_neck_conv_image_bytes.argtypes = [i, i, i]
@@ -154,6 +160,7 @@ EXPORTED = [
     "lsam_mlp_block_fwd", "lsam_tail_block_image_bytes", "lsam_tail_block_vec_floats", "lsam_tail_block_pack",
     "lsam_tail_block_fwd", "lsam_patch_embed_image_bytes", "lsam_patch_embed_pack", "lsam_patch_embed_fwd", "lsam_linear_maxpool2x2",
     "lsam_lateral_conv_image_bytes", "lsam_lateral_conv_pack", "lsam_lateral_conv_fwd", "lsam_mlp_block_fwd_next_norm", "lsam_attention_fwd_pooled_q",
+    "lsam_add_rows", "lsam_mha_fwd", "lsam_pe_encode", "lsam_upscale2x2_fwd", "lsam_mask_gate", "lsam_bilinear_upsample",
     "lsam_attention_bwd_qpool", "lsam_neck_conv_image_bytes", "lsam_neck_conv_pack", "lsam_neck_level_fwd",
     "lsam_neck_topdown_bwd", "lsam_outer_reduce_static_max_ws", "lsam_outer_reduce_static_init", "lsam_outer_reduce_static",
 ]

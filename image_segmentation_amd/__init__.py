@@ -5,3 +5,5 @@ from .hieradet import Hiera, MultiScaleAttention, MultiScaleBlock, PatchEmbed, M
 from .image_encoder import FpnNeck, ImageEncoder, PositionEmbeddingSine, build_image_encoder, forward_image  # noqa: F401
 from .lora_qkv import (LoRA_qkv, LoRABank, custom_load_lora_parameters, custom_save_lora_parameters,  # noqa: F401
                        wrap_image_encoder_lora)
+from .sam_heads import (Attention, Attention_LoRA, MaskDecoder, PromptEncoder, SAM2Base, TwoWayAttentionBlock,  # noqa: F401
+                        TwoWayTransformer, wrap_decoder_lora)

@@ -146,6 +146,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_t<sizeof(T) == 2>(x[r]);
             }
+            if (flags & LSAM_EPI_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (flags & LSAM_EPI_SIGMOID) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = 1.0f / (1.0f + expf(-v[r]));
+            }
             if (p.res) v += load4(p.res + rm * p.ldres + n);
             if (out_f32)
                 store4(static_cast<float*>(p.out) + (size_t)m * p.ldo + n, v);
@@ -1120,6 +1128,11 @@ template <typename T> int launch_gemm(const GemmArgs& a, hipStream_t s) {
             }
             return LSAM_OK;
         }
+    }
+    // ReLU / sigmoid epilogues (the SAM heads' small MLPs) exist in the generic kernel only
+    if (a.flags & (LSAM_EPI_RELU | LSAM_EPI_SIGMOID)) {
+        LSAM_REQUIRE(a.pool_w == 0, LSAM_ERR_UNSUPPORTED, "linear: ReLU / sigmoid with the pooled epilogue");
+        return a.N % 112 == 0 ? launch_cfg<T, 2, 7, 4, 1>(a, s) : launch_cfg<T, 4, 4, 2, 2>(a, s);
     }
     if (a.pool_w > 0) {
         if constexpr (sizeof(T) == 2) {

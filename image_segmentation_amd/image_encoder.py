@@ -111,24 +111,34 @@ class _NeckFn(torch.autograd.Function):
         prev = None
         ctx.chain = []            # (local) levels, fine -> coarse, whose gradient flows into the next coarser one
         dep = [False] * (n + 2)
+        # precision policy (FpnNeck.precise_top_down): the levels of the top-down chain -- 5 % of the neck's FLOPs, and what
+        # the SAM transformer reads -- take fp32 operands (the trunk's fp32 stage outputs as they are, fp32 weights) and
+        # round ONCE, at the output; the bf16 kernels would round inputs, weights and outputs (0.33 % vs 0.17 % error)
+        precise = dt != torch.float32 and neck.precise_top_down
+        pack32 = neck._pack_for(torch.float32, xs[0].device) if precise else None
         for i in range(n, -1, -1):
             x = xs[i]
             co = neck.d_model
+            hi = precise and (base + i) in neck.fpn_top_down_levels
+            pk, ldt = (pack32, torch.float32) if hi else (pack, dt)
             top = prev if ((base + i) in neck.fpn_top_down_levels and prev is not None) else None
+            if top is not None and top.dtype != ldt:
+                top = ops.cast(top.view(-1, co), ldt).view(top.shape)
             j = n - i             # convs[n_levels - 1 - level] (image_encoder.py:114): index from the coarse end
-            if pack.lat_img[j] is not None and top is None:
+            if pk.lat_img[j] is not None and top is None:
                 N, H, W, K = x.shape
-                out = ops.lateral_conv_fwd(x.reshape(-1, K), pack.lat_img[j], pack.bias[j], co).view(N, H, W, co)
+                out = ops.lateral_conv_fwd(x.reshape(-1, K), pk.lat_img[j], pk.bias[j], co).view(N, H, W, co)
             else:
-                img = pack.img[j] if pack.img[j] is not None else None
+                img = pk.img[j] if pk.img[j] is not None else None
                 if img is None:
-                    img = pack.img[j] = ops.neck_conv_pack(neck.convs[j].conv.weight.detach().float(), dt)
-                out = ops.neck_level_fwd(x, img, pack.bias[j], dt, co, top)
+                    img = pk.img[j] = ops.neck_conv_pack(neck.convs[j].conv.weight.detach().float(), ldt)
+                out = ops.neck_level_fwd(x, img, pk.bias[j], ldt, co, top)
             if top is not None:
                 ctx.chain.append(i)
             # only levels fed (through top-down adds) by the LAST stage output depend on a differentiable input
             dep[i] = i == n or (top is not None and dep[i + 1])
-            outs[i] = prev = out
+            prev = out
+            outs[i] = ops.cast(out.view(-1, co), dt).view(out.shape) if out.dtype != dt else out
         ctx.pack, ctx.dt, ctx.n = pack, dt, n
         ctx.x_last_shape = tuple(xs[n].shape)
         ctx.set_materialize_grads(False)
@@ -190,6 +200,7 @@ class FpnNeck(nn.Module):
         self.fpn_top_down_levels = list(fpn_top_down_levels)
         self._packs = {}
         self._pack_epoch = 0
+        self.precise_top_down = True      # see _NeckFn.forward; False = every level in the autocast dtype
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed())
 
     def invalidate_packed(self):

@@ -64,7 +64,8 @@ def pack_matrix(src: torch.Tensor, dtype: torch.dtype, ld: Optional[int] = None)
 def linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
            res: Optional[torch.Tensor] = None, res_row_mod: int = 0, gelu: bool = False,
            gelu_bwd_aux: Optional[torch.Tensor] = None, out_f32: bool = False, save_pre: bool = False,
-           out: Optional[torch.Tensor] = None, K: Optional[int] = None, N: Optional[int] = None):
+           out: Optional[torch.Tensor] = None, K: Optional[int] = None, N: Optional[int] = None, relu: bool = False,
+           sigmoid: bool = False):
     """out = epilogue(A[:, :K] @ W[:N, :K].T + bias) + res   (see lsam_linear)."""
     _need_gpu(A, W, bias, res)
     assert A.dtype == W.dtype
@@ -80,7 +81,8 @@ def linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None
     _, _, ldo = _rows2d(out)
     out2 = torch.empty(M, N, dtype=A.dtype, device=A.device) if save_pre else None
     flags = (_C.EPI_GELU if gelu else 0) | (_C.EPI_GELU_BWD if gelu_bwd_aux is not None else 0) | \
-        (_C.EPI_OUT_F32 if out_f32 else 0) | (_C.EPI_SAVE_PRE if save_pre else 0)
+        (_C.EPI_OUT_F32 if out_f32 else 0) | (_C.EPI_SAVE_PRE if save_pre else 0) | (_C.EPI_RELU if relu else 0) | \
+        (_C.EPI_SIGMOID if sigmoid else 0)
     ldres = res.stride(0) if res is not None else 0
     ldaux = gelu_bwd_aux.stride(0) if gelu_bwd_aux is not None else 0
     check(lib().lsam_linear(dtype_code(A.dtype), ptr(A), lda, ptr(W), ldw, ptr(bias), ptr(res), ldres,
@@ -423,4 +425,73 @@ def neck_topdown_bwd(g_fine: torch.Tensor, g_coarse: Optional[torch.Tensor] = No
         assert g_coarse.dtype == g_fine.dtype and g_coarse.is_contiguous() and g_coarse.shape == out.shape
     check(lib().lsam_neck_topdown_bwd(dtype_code(g_fine.dtype), ptr(g_fine), ptr(g_coarse), ptr(out), N, H // 2, W // 2, Cc,
                                       stream()))
+    return out
+
+
+# ---- SAM heads pieces (csrc/heads.hip) ---------------------------------------------------------------------------
+def add_rows(a: torch.Tensor, b: Optional[torch.Tensor], out_dtype: torch.dtype) -> torch.Tensor:
+    """out[m] = a[m] + b[m % rows(b)] as out_dtype; a fp32 / bf16 [M, C] (row-major), b fp32 [R, C] or None (a cast)."""
+    _need_gpu(a, b)
+    M, Cc, lda = _rows2d(a)
+    b = _f32rows(b)
+    out = torch.empty(M, Cc, dtype=out_dtype, device=a.device)
+    check(lib().lsam_add_rows(dtype_code(a.dtype), ptr(a), lda, ptr(b), b.stride(0) if b is not None else 0,
+                              b.shape[0] if b is not None else 1, dtype_code(out_dtype), ptr(out), Cc, M, Cc, stream()))
+    return out
+
+
+def mha(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, nh: int) -> torch.Tensor:
+    """softmax(q k^T / sqrt(hd)) v for q [B, nq, C], k / v [B, nk, C] (contiguous, same dtype), C = nh * hd."""
+    _need_gpu(q, k, v)
+    assert q.dim() == 3 and k.dim() == 3 and v.dim() == 3 and q.dtype == k.dtype == v.dtype
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    B, nq, Cc = q.shape
+    nk = k.shape[1]
+    out = torch.empty_like(q)
+    check(lib().lsam_mha_fwd(dtype_code(q.dtype), ptr(q), Cc, nq * Cc, ptr(k), Cc, nk * Cc, ptr(v), Cc, nk * Cc, ptr(out), Cc,
+                             nq * Cc, B, nq, nk, nh, Cc // nh, stream()))
+    return out
+
+
+def pe_encode(gauss: torch.Tensor, coords01: torch.Tensor) -> torch.Tensor:
+    """[M, 2F] = [sin | cos](2 pi (2 c - 1) @ gauss) for gauss fp32 [2, F], coords01 fp32 [M, 2]."""
+    _need_gpu(gauss, coords01)
+    g, c = _f32c(gauss), _f32c(coords01)
+    M, F_ = c.shape[0], g.shape[1]
+    out = torch.empty(M, 2 * F_, dtype=torch.float32, device=c.device)
+    check(lib().lsam_pe_encode(ptr(g), ptr(c), ptr(out), M, F_, stream()))
+    return out
+
+
+def upscale2x2(g: torch.Tensor, skip: Optional[torch.Tensor], ln: Optional[Tuple[torch.Tensor, torch.Tensor]], eps: float,
+               B: int, H: int, W: int, Cc: int, dtype: torch.dtype) -> torch.Tensor:
+    """T [B, 2H, 2W, C] = GELU(LN2d?(pixel_shuffle(g) + skip)) for g fp32 [B*H*W, 4C] (see lsam_upscale2x2_fwd)."""
+    _need_gpu(g, skip)
+    assert g.dtype == torch.float32 and g.is_contiguous() and tuple(g.shape) == (B * H * W, 4 * Cc)
+    if skip is not None:
+        assert skip.dtype == dtype and skip.is_contiguous() and skip.numel() == B * 4 * H * W * Cc
+    w, b = (_f32c(ln[0]), _f32c(ln[1])) if ln is not None else (None, None)
+    out = torch.empty(B, 2 * H, 2 * W, Cc, dtype=dtype, device=g.device)
+    check(lib().lsam_upscale2x2_fwd(dtype_code(dtype), ptr(g), ptr(skip), ptr(w), ptr(b), eps, ptr(out), B, H, W, Cc, stream()))
+    return out
+
+
+def mask_gate(logits: torch.Tensor, obj: Optional[torch.Tensor], first: int, n_masks: int, no_obj: float) -> torch.Tensor:
+    """fp32 [B, n_masks, HW] from logits fp32 [B, HW, L]: columns first.., replaced by no_obj where obj[b] <= 0."""
+    _need_gpu(logits, obj)
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and logits.dim() == 3
+    B, HW, L = logits.shape
+    o = _f32c(obj.reshape(-1)) if obj is not None else None
+    out = torch.empty(B, n_masks, HW, dtype=torch.float32, device=logits.device)
+    check(lib().lsam_mask_gate(ptr(logits), L, ptr(o), ptr(out), B, HW, first, n_masks, no_obj, stream()))
+    return out
+
+
+def bilinear_upsample(x: torch.Tensor, scale: int) -> torch.Tensor:
+    """F.interpolate(x, scale_factor=scale, mode='bilinear', align_corners=False) for fp32 [B, C, H, W]."""
+    _need_gpu(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    B, Cc, H, W = x.shape
+    out = torch.empty(B, Cc, H * scale, W * scale, dtype=torch.float32, device=x.device)
+    check(lib().lsam_bilinear_upsample(ptr(x), ptr(out), B * Cc, H, W, scale, stream()))
     return out
