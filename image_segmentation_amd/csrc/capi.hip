@@ -168,6 +168,15 @@ int lsam_neck_topdown_bwd(int dtype, const void* g_fine, const void* g_coarse, v
     DISPATCH(dtype, launch_neck_topdown_bwd<float>(g_fine, g_coarse, out, N, Hc, Wc, C, s),
              launch_neck_topdown_bwd<bf16>(g_fine, g_coarse, out, N, Hc, Wc, C, s));
 }
+size_t lsam_neck_conv_split_image_bytes(int in_channels, int out_channels) { return neck_split_image_bytes(in_channels, out_channels); }
+int lsam_neck_conv_pack_split(const float* weight, int in_channels, int out_channels, void* image, lsam_stream_t stream) {
+    return launch_pack_neck_split(weight, in_channels, out_channels, image, static_cast<hipStream_t>(stream));
+}
+int lsam_neck_level_fwd_split(const float* x, const void* image, const float* bias, const float* top32, void* out, float* out32,
+                              int N, int H, int W, int in_channels, int out_channels, lsam_stream_t stream) {
+    return launch_neck_level_split(x, image, bias, top32, out, out32, N, H, W, in_channels, out_channels,
+                                   static_cast<hipStream_t>(stream));
+}
 
 size_t lsam_window_block_image_bytes(int nh) { return (nh == 1 || nh == 2) ? winblock_image_bytes(nh) : 0; }
 size_t lsam_window_block_bias_floats(int nh) { return (nh == 1 || nh == 2) ? winblock_bias_floats(nh) : 0; }

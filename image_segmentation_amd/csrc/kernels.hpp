@@ -103,6 +103,11 @@ template <typename T> int launch_pack_neck(const float* w, int K, int N, void* i
 template <typename T>
 int launch_neck_level(const float* x, const void* img, const float* bias, const void* top, void* out, int Nimg, int H, int W,
                       int K, int N, hipStream_t s);
+// the same with two-term bf16 operands (fp32-accurate product), fp32 top-down addend / second output
+size_t neck_split_image_bytes(int K, int N);
+int launch_pack_neck_split(const float* w, int K, int N, void* img, hipStream_t s);
+int launch_neck_level_split(const float* x, const void* img, const float* bias, const float* top, void* out, float* out32,
+                            int Nimg, int H, int W, int K, int N, hipStream_t s);
 template <typename T>
 int launch_neck_topdown_bwd(const void* gf, const void* gc, void* out, int Nimg, int Hc, int Wc, int C, hipStream_t s);
 

@@ -83,6 +83,7 @@ class _NeckPack:
     def __init__(self, neck: "FpnNeck", dt: torch.dtype, device: torch.device):
         self.sig = neck._pack_signature()
         self.img, self.bias, self.lat_img = [], [], []
+        self.split_img = [None] * len(neck.convs)     # [hi | lo] images of the top-down levels, built on first use
         for seq in neck.convs:
             w, b = seq.conv.weight.detach(), seq.conv.bias.detach()
             w = w.to(device=device, dtype=torch.float32).reshape(w.shape[0], w.shape[1]).contiguous()
@@ -111,34 +112,41 @@ class _NeckFn(torch.autograd.Function):
         prev = None
         ctx.chain = []            # (local) levels, fine -> coarse, whose gradient flows into the next coarser one
         dep = [False] * (n + 2)
-        # precision policy (FpnNeck.precise_top_down): the levels of the top-down chain -- 5 % of the neck's FLOPs, and what
-        # the SAM transformer reads -- take fp32 operands (the trunk's fp32 stage outputs as they are, fp32 weights) and
-        # round ONCE, at the output; the bf16 kernels would round inputs, weights and outputs (0.33 % vs 0.17 % error)
-        precise = dt != torch.float32 and neck.precise_top_down
-        pack32 = neck._pack_for(torch.float32, xs[0].device) if precise else None
+        # precision policy (FpnNeck.precise_top_down): under bf16, the levels of the top-down chain -- 5 % of the neck's
+        # FLOPs, and what the SAM transformer reads -- use two-term bf16 operands (fp32-accurate products, fp32 top-down
+        # addends) and round ONCE, at the bf16 store; plain bf16 would round inputs, weights and outputs (0.33 % against
+        # 0.17 % error on the level the masks come from: mask IoU 0.989 against 0.993 on the north-star fixture)
+        precise = dt == torch.bfloat16 and neck.precise_top_down and neck.d_model == 256
+        prev32 = None
         for i in range(n, -1, -1):
             x = xs[i]
             co = neck.d_model
-            hi = precise and (base + i) in neck.fpn_top_down_levels
-            pk, ldt = (pack32, torch.float32) if hi else (pack, dt)
-            top = prev if ((base + i) in neck.fpn_top_down_levels and prev is not None) else None
-            if top is not None and top.dtype != ldt:
-                top = ops.cast(top.view(-1, co), ldt).view(top.shape)
+            in_chain = (base + i) in neck.fpn_top_down_levels
+            top = prev if (in_chain and prev is not None) else None
             j = n - i             # convs[n_levels - 1 - level] (image_encoder.py:114): index from the coarse end
-            if pk.lat_img[j] is not None and top is None:
+            if precise and in_chain:
+                if pack.split_img[j] is None:
+                    pack.split_img[j] = ops.neck_conv_pack_split(neck.convs[j].conv.weight)
+                t32 = None
+                if top is not None:
+                    t32 = prev32 if prev32 is not None else ops.cast(top.view(-1, co), torch.float32).view(top.shape)
+                feeds_finer = i > 0 and (base + i - 1) in neck.fpn_top_down_levels
+                out, prev32 = ops.neck_level_fwd_split(x, pack.split_img[j], pack.bias[j], co, t32, want32=feeds_finer)
+            elif pack.lat_img[j] is not None and top is None:
                 N, H, W, K = x.shape
-                out = ops.lateral_conv_fwd(x.reshape(-1, K), pk.lat_img[j], pk.bias[j], co).view(N, H, W, co)
+                out = ops.lateral_conv_fwd(x.reshape(-1, K), pack.lat_img[j], pack.bias[j], co).view(N, H, W, co)
+                prev32 = None
             else:
-                img = pk.img[j] if pk.img[j] is not None else None
+                img = pack.img[j] if pack.img[j] is not None else None
                 if img is None:
-                    img = pk.img[j] = ops.neck_conv_pack(neck.convs[j].conv.weight.detach().float(), ldt)
-                out = ops.neck_level_fwd(x, img, pk.bias[j], ldt, co, top)
+                    img = pack.img[j] = ops.neck_conv_pack(neck.convs[j].conv.weight.detach().float(), dt)
+                out = ops.neck_level_fwd(x, img, pack.bias[j], dt, co, top)
+                prev32 = None
             if top is not None:
                 ctx.chain.append(i)
             # only levels fed (through top-down adds) by the LAST stage output depend on a differentiable input
             dep[i] = i == n or (top is not None and dep[i + 1])
-            prev = out
-            outs[i] = ops.cast(out.view(-1, co), dt).view(out.shape) if out.dtype != dt else out
+            outs[i] = prev = out
         ctx.pack, ctx.dt, ctx.n = pack, dt, n
         ctx.x_last_shape = tuple(xs[n].shape)
         ctx.set_materialize_grads(False)

@@ -415,6 +415,35 @@ def neck_level_fwd(x_nhwc: torch.Tensor, img: torch.Tensor, bias: torch.Tensor, 
     return out
 
 
+def neck_conv_pack_split(weight: torch.Tensor) -> torch.Tensor:
+    """[hi | lo] bf16 fragment image of a [co, K] (or [co, K, 1, 1]) convolution weight for neck_level_fwd_split."""
+    _need_gpu(weight)
+    w = weight.detach().to(torch.float32).reshape(weight.shape[0], -1).contiguous()
+    co, K = w.shape
+    nbytes = lib().lsam_neck_conv_split_image_bytes(K, co)
+    if nbytes == 0:
+        raise _C.LsamError(f"neck_conv_pack_split: {K} -> {co} channels not supported")
+    img = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
+    check(lib().lsam_neck_conv_pack_split(ptr(w), K, co, ptr(img), stream()))
+    return img
+
+
+def neck_level_fwd_split(x_nhwc: torch.Tensor, img: torch.Tensor, bias: torch.Tensor, co: int,
+                         top32: Optional[torch.Tensor] = None, want32: bool = False):
+    """(bf16 out, fp32 out or None) = lateral conv (+ nearest-x2 top-down add of the fp32 `top32`) with two-term bf16
+    operands: fp32-accurate product, one rounding at the bf16 store (see lsam_neck_level_fwd_split)."""
+    _need_gpu(x_nhwc, img, bias, top32)
+    assert x_nhwc.dtype == torch.float32 and x_nhwc.is_contiguous() and x_nhwc.dim() == 4
+    N, H, W, K = x_nhwc.shape
+    if top32 is not None:
+        assert top32.dtype == torch.float32 and top32.is_contiguous() and tuple(top32.shape) == (N, H // 2, W // 2, co)
+    out = torch.empty(N, H, W, co, dtype=torch.bfloat16, device=x_nhwc.device)
+    out32 = torch.empty(N, H, W, co, dtype=torch.float32, device=x_nhwc.device) if want32 else None
+    check(lib().lsam_neck_level_fwd_split(ptr(x_nhwc), ptr(img), ptr(_f32c(bias)), ptr(top32), ptr(out), ptr(out32), N, H, W, K, co,
+                                          stream()))
+    return out, out32
+
+
 def neck_topdown_bwd(g_fine: torch.Tensor, g_coarse: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Adjoint of the nearest-x2 upsample: [N,H/2,W/2,C] = 2x2 sums of g_fine [N,H,W,C] (+ g_coarse)."""
     _need_gpu(g_fine, g_coarse)

@@ -174,6 +174,17 @@ int lsam_neck_level_fwd(int dtype, const float* x, const void* image, const floa
 int lsam_neck_topdown_bwd(int dtype, const void* g_fine, const void* g_coarse, void* out, int N, int Hc, int Wc, int C,
                           lsam_stream_t stream);
 
+/* The same level (image_encoder.py:102-134) with fp32-ACCURATE products on the bf16 matrix pipe, for the levels of the
+ * top-down chain under bf16 autocast: operands are split in two bf16 terms (x = xh + xl, W = Wh + Wl; three MFMAs per
+ * step), the top-down addend `top32` and the optional second output `out32` (the next finer level's addend) are fp32, and
+ * `out` (bf16 NHWC) is rounded once.  The reference's autocast convolution rounds inputs, weights and output; this level
+ * feeds the SAM transformer, and the extra roundings cost 0.4 points of mask IoU against the reference's fp32 masks.
+ * out_channels == 256 only; image from lsam_neck_conv_pack_split (lsam_neck_conv_split_image_bytes bytes). */
+size_t lsam_neck_conv_split_image_bytes(int in_channels, int out_channels);
+int lsam_neck_conv_pack_split(const float* weight, int in_channels, int out_channels, void* image, lsam_stream_t stream);
+int lsam_neck_level_fwd_split(const float* x, const void* image, const float* bias, const float* top32, void* out, float* out32,
+                              int N, int H, int W, int in_channels, int out_channels, lsam_stream_t stream);
+
 /* ---- SAM prompt encoder / mask decoder pieces (SAM2Base._forward_sam_heads, sam2_base.py:257-413) that are not a
  * Linear or a LayerNorm.  See image_segmentation_amd/sam_heads.py for the composition. ---- */
 /* out[m][c] = (T_out)(a[m][c] + b[m % b_rows][c]); b nullable (then a dtype conversion).  `queries + query_pe`,

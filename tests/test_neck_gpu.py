@@ -36,6 +36,29 @@ def test_neck_level_kernel(dt, tol, K, co, with_top):
     assert rel_err(got.float(), ref) < tol
 
 
+@pytest.mark.parametrize("K", [448, 896, 1152, 56])
+@pytest.mark.parametrize("N,H,W", [(2, 10, 6), (9, 64, 64)])         # ragged small grid; 36864 tokens (the 64-token tile variant)
+def test_neck_level_split_kernel(K, N, H, W):
+    """Two-term bf16 operands: the product is fp32-accurate (no operand rounding), the bf16 output is rounded once."""
+    from image_segmentation_amd import ops
+    co = 256
+    x = rnd(N, H, W, K, seed=K)
+    w = rnd(co, K, seed=co) / K ** 0.5
+    b = rnd(co, seed=3)
+    top = rnd(N, H // 2, W // 2, co, seed=4)
+    img = ops.neck_conv_pack_split(w.cuda())
+    ref = x.double() @ w.double().T + b.double()
+    out, out32 = ops.neck_level_fwd_split(x.cuda(), img, b.cuda(), co, None, want32=True)
+    assert out.dtype == torch.bfloat16 and out32.dtype == torch.float32 and tuple(out.shape) == (N, H, W, co)
+    assert rel_err(out32, ref) < 2e-5                      # 2^-16-class: the dropped lo.lo term and the bf16 lo roundings
+    assert torch.equal(out, out32.bfloat16())              # one rounding
+    ref = ref + F.interpolate(top.double().permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest").permute(0, 2, 3, 1)
+    out, none = ops.neck_level_fwd_split(x.cuda(), img, b.cuda(), co, top.cuda(), want32=False)
+    assert none is None
+    assert rel_err(out.float(), ref) < 2.5e-3              # bf16 output rounding alone (plain bf16 operands: 6e-3 bound above)
+    assert rel_err(out.float(), ref.float().bfloat16().float()) < 3e-4   # and almost always the SAME bf16 value as exact
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_neck_topdown_adjoint(dt):
     from image_segmentation_amd import ops
