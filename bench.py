@@ -58,6 +58,7 @@ KERNEL_NAMES = {
     5000: ("global attention (attn2_fwd)", "flop"),
     5001: ("window attention (attnw / attn2 / attn_fwd)", "flop"),
     5002: ("attention backward (LoRA blocks)", "flop"),
+    5003: ("kvattn: k|v projection + 8x8-window attention of the q-pool block 2, one kernel", "flop"),
     100: ("ln_fwd", "byte"), 101: ("ln_bwd", "byte"), 102: ("cast fp32->bf16", "byte"),
     103: ("lateral 1x1 conv (levels 0/1)", "byte"), 104: ("patch_embed 7x7/4 conv + pos", "byte"),
     105: ("winblock stage-1 attention half", "byte"), 106: ("mlpblock stage-1 MLP half", "byte"),

@@ -178,6 +178,24 @@ int lsam_neck_level_fwd_split(const float* x, const void* image, const float* bi
                                    static_cast<hipStream_t>(stream));
 }
 
+size_t lsam_kv_window_attention_image_bytes(int dim, int nh, int hd) {
+    return kvattn_supported(8, 8, 8, 2, nh, hd, dim, nh * hd) ? kvattn_image_bytes() : 0;
+}
+int lsam_kv_window_attention_pack(const float* qkv_w, const float* qkv_b, int dim, int nh, int hd, void* image,
+                                  lsam_stream_t stream) {
+    return launch_pack_kvattn(qkv_w, qkv_b, dim, nh, hd, image, static_cast<hipStream_t>(stream));
+}
+int lsam_kv_window_attention_fwd(const void* xn, int ldx, const float* q_pooled, int ldq, const void* image, void* out, int ldo,
+                                 int N, int H, int W, int dim, int nh, int hd, lsam_stream_t stream) {
+    if (!kvattn_supported(H, W, 8, 2, nh, hd, dim, nh * hd)) {
+        set_error("kv_window_attention: grid %dx%d, %d heads of %d over %d channels not supported", H, W, nh, hd, dim);
+        return LSAM_ERR_UNSUPPORTED;
+    }
+    KvAttnArgs a{static_cast<const bf16*>(xn), ldx, q_pooled, ldq, static_cast<const char*>(image), static_cast<bf16*>(out), ldo,
+                 N, H, W, dim, hd, (1.0f / sqrtf((float)hd)) * 1.4426950408889634f};
+    return launch_kvattn(a, static_cast<hipStream_t>(stream));
+}
+
 size_t lsam_window_block_image_bytes(int nh) { return (nh == 1 || nh == 2) ? winblock_image_bytes(nh) : 0; }
 size_t lsam_window_block_bias_floats(int nh) { return (nh == 1 || nh == 2) ? winblock_bias_floats(nh) : 0; }
 int lsam_window_block_pack(const float* qkv_w, const float* qkv_b, const float* proj_w, const float* proj_b, int nh,

@@ -32,6 +32,7 @@ struct BlockGeom {
     bool fused_attn;  // bf16 only: LN1 + qkv + window attention + proj + residual in one kernel (winblock.hip)
     bool fused_mlp;   // bf16 only: LN2 + fc1 + GELU + fc2 + residual in one kernel (mlpblock.hip)
     bool fused_tail;  // bf16 only: proj + residual + LN2 + MLP + residual (+ next block's LN1) in one kernel (tailblock.hip)
+    bool fused_kv;    // bf16 only: k | v projection + 8x8-window attention of a q-pool stage-entry block in one kernel (kvattn.hip)
 };
 struct BlockOff {
     size_t ln1w, ln1b, wqkv, bqkv, wproj, bproj, ln2w, ln2b, w1, b1, w2, b2, wsc, bsc;
@@ -40,6 +41,7 @@ struct BlockOff {
     size_t wimg, wbias;  // fused window-block weight image + padded biases (winblock.hip), if g.fused_attn
     size_t mimg, mbias;  // fused MLP weight image + fc2 bias (mlpblock.hip), if g.fused_mlp
     size_t timg, tvec;   // fused tail weight stream + packed vectors (tailblock.hip), if g.fused_tail
+    size_t kvimg;        // k | v weight image of the fused projection + attention kernel (kvattn.hip), if g.fused_kv
 };
 
 }  // namespace lsam
@@ -228,6 +230,8 @@ static int pack_t(lsam_hiera* h, const lsam_block_params_t* bp, const float* pat
         if (g.fused_tail)
             LSAM_TRY(launch_pack_tailblock(p.attn_proj_w, p.attn_proj_b, p.norm2_w, p.norm2_b, p.fc1_w, p.fc1_b, p.fc2_w,
                                            p.fc2_b, q, at<char>(arena, o.timg), at<float>(arena, o.tvec), s));
+        if (g.fused_kv)
+            LSAM_TRY(launch_pack_kvattn(p.qkv_w, p.qkv_b, d, g.heads, q / g.heads, at<char>(arena, o.kvimg), s));
         if (g.lora) {  // transposed copies for dX = dY . W   (frozen: no dW GEMMs exist)
             LSAM_TRY(launch_pack_matrix<T>(p.fc2_w, 1, 4 * q, 4 * q, q, at<T>(arena, o.w2T), q, s));
             LSAM_TRY(launch_pack_matrix<T>(p.fc1_w, 1, q, q, 4 * q, at<T>(arena, o.w1T), 4 * q, s));
@@ -342,19 +346,29 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
             gq.pool_h = g.gin;
             gq.pool_w = g.gin;
             LSAM_TRY(launch_gemm<T>(gq, s));
-            LSAM_TRY(linear<T>(xn, g.kq, at<T>(arena, o.wqkv) + (size_t)q * g.kq, g.kq, at<float>(arena, o.bqkv) + q, nullptr, 0,
-                               0, nullptr, 0, qkv + q, 3 * q, nullptr, 0, 0, Mi, 2 * q, g.kq, s));
+            if (!g.fused_kv)
+                LSAM_TRY(linear<T>(xn, g.kq, at<T>(arena, o.wqkv) + (size_t)q * g.kq, g.kq, at<float>(arena, o.bqkv) + q, nullptr, 0,
+                                   0, nullptr, 0, qkv + q, 3 * q, nullptr, 0, 0, Mi, 2 * q, g.kq, s));
         } else {
             LSAM_TRY(linear<T>(xn, g.kq, at<T>(arena, o.wqkv), g.kq, at<float>(arena, o.bqkv), nullptr, 0, 0, nullptr, 0,
                                qkv, 3 * q, nullptr, 0, 0, Mi, 3 * q, g.kq, s));
         }
         // ---- attention ------------------------------------------------------------------------------
         T* a = at<T>(ws, w.a);
+        if (qpooled && g.fused_kv) {
+            // k | v of the window's 64 tokens are projected inside the attention kernel: they never cross HBM
+            if constexpr (sizeof(T) == 2) {
+                KvAttnArgs ka{xn, g.kq, qp, q, at<char>(arena, o.kvimg), a, q, N, g.gin, g.gin, d, q / g.heads,
+                              (1.0f / sqrtf((float)(q / g.heads))) * 1.4426950408889634f};
+                LSAM_TRY(launch_kvattn(ka, s));
+            }
+        } else {
         AttnArgs aa{qkv, 3 * q, at<float>(arena, o.bqkv), a, q, grad ? at<float>(ws, w.sv[gi].lse) : nullptr,
                     N, g.gin, g.gin, g.ws, g.pool, g.heads, q / g.heads, at<T>(arena, o.bqkvT)};
         aa.qpool = qp;
         aa.ldqp = q;
         LSAM_TRY(launch_attn_fwd<T>(aa, s));
+        }
         if (g.fused_tail) {   // proj + residual + norm2 + MLP + residual (+ the next block's norm1), one kernel
             const bool next_ln = !last && !h->blk[i + 1].fused_attn && !h->blk[i + 1].lora && h->blk[i + 1].dim == q;
             TailBlockArgs ta{a, q, res, y, at<char>(arena, o.timg), at<float>(arena, o.tvec),
@@ -539,6 +553,10 @@ int lsam_hiera_create(const lsam_hiera_config_t* c, lsam_hiera_t** out) {
                        winblock_supported(g.gin, g.gin, g.ws, g.pool, g.heads, g.dout / g.heads, g.dim, g.dout);
         g.fused_tail = c->dtype == LSAM_BF16 && !g.lora && !g.fused_attn && tailblock_supported(g.dout);
         g.fused_mlp = c->dtype == LSAM_BF16 && !g.lora && !g.fused_tail && mlpblock_supported(g.dout);
+        // (the conditions under which forward_t takes the pooled-query path, plus the kernel's own)
+        g.fused_kv = c->dtype == LSAM_BF16 && !g.lora && g.dim != g.dout && g.dout % g.heads == 0 &&
+                     kvattn_supported(g.gin, g.gin, g.ws, g.pool, g.heads, g.dout / g.heads, g.dim, g.dout) &&
+                     gemm_pool_supported(g.gin, g.gin, g.dout) && (2 * g.dout) % 224 == 0;
         h->blk.push_back(g);
         dim = g.dout;
         grid = g.gout;
@@ -611,6 +629,7 @@ int lsam_hiera_create(const lsam_hiera_config_t* c, lsam_hiera_t** out) {
             o.timg = b.take(tailblock_image_bytes(g.dout));
             o.tvec = b.take(tailblock_vec_floats(g.dout) * 4);
         }
+        if (g.fused_kv) o.kvimg = b.take(kvattn_image_bytes());
         if (g.lora) {
             o.w2T = b.take(4 * q * q * e);
             o.w1T = b.take(4 * q * q * e);

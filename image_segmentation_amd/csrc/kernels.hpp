@@ -29,7 +29,7 @@ void prof_end(int rec, hipStream_t s, double flops, int cfg, int m, int n, int k
 enum {
     PROF_LN_FWD = 100, PROF_LN_BWD = 101, PROF_CAST = 102, PROF_LATERAL = 103, PROF_PATCH_EMBED = 104, PROF_WINBLOCK = 105,
     PROF_MLPBLOCK = 106, PROF_MAXPOOL = 107, PROF_SPATIAL_MEAN = 108, PROF_OUTER = 109, PROF_NECK = 110,
-    PROF_ATTN_SMALL = 111,                                      /* windows with <= 16 queries per wave: bytes */
+    PROF_ATTN_SMALL = 111, PROF_KVATTN = 5003,                                      /* windows with <= 16 queries per wave: bytes */
     PROF_ATTN_GLOBAL = 5000, PROF_ATTN_WIN = 5001, PROF_ATTN_BWD = 5002   /* FLOPs */
 };
 struct ProfScope {
@@ -110,6 +110,20 @@ int launch_neck_level_split(const float* x, const void* img, const float* bias, 
                             int Nimg, int H, int W, int K, int N, hipStream_t s);
 template <typename T>
 int launch_neck_topdown_bwd(const void* gf, const void* gc, void* out, int Nimg, int Hc, int Wc, int C, hipStream_t s);
+
+// fused k | v projection + window attention of a q-pool stage-entry block with 8x8 windows (kvattn.hip)
+struct KvAttnArgs {
+    const bf16* xn; int ldx;      // LN1 output rows [N*H*W][dim]
+    const float* qp; int ldqp;    // pooled queries, fp32 [N*(H/2)*(W/2)][nh*hd] (lsam_linear_maxpool2x2)
+    const char* img;              // launch_pack_kvattn
+    bf16* out; int ldo;           // attention output [N*(H/2)*(W/2)][nh*hd]
+    int N, H, W, dim, hd;
+    float c_log2;                 // log2(e) / sqrt(hd)
+};
+size_t kvattn_image_bytes();
+bool kvattn_supported(int H, int W, int ws, int pool, int nh, int hd, int dim, int dout);
+int launch_pack_kvattn(const float* wqkv, const float* bqkv, int dim, int nh, int hd, void* img, hipStream_t s);
+int launch_kvattn(const KvAttnArgs& a, hipStream_t s);
 
 // fused attention half of a same-dim 8x8-window block (winblock.hip)
 struct WinBlockArgs {

@@ -457,6 +457,33 @@ def neck_topdown_bwd(g_fine: torch.Tensor, g_coarse: Optional[torch.Tensor] = No
     return out
 
 
+def kv_window_attention_pack(qkv_w: torch.Tensor, qkv_b: torch.Tensor, nh: int) -> torch.Tensor:
+    """Weight image of kv_window_attention_fwd from qkv.weight [3*nh*hd, dim] and qkv.bias."""
+    _need_gpu(qkv_w, qkv_b)
+    w, b = _f32c(qkv_w), _f32c(qkv_b)
+    dim, hd = w.shape[1], w.shape[0] // (3 * nh)
+    nbytes = lib().lsam_kv_window_attention_image_bytes(dim, nh, hd)
+    if nbytes == 0:
+        raise _C.LsamError(f"kv_window_attention: {nh} heads of {hd} over {dim} channels not supported")
+    img = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    check(lib().lsam_kv_window_attention_pack(ptr(w), ptr(b), dim, nh, hd, ptr(img), stream()))
+    return img
+
+
+def kv_window_attention_fwd(xn: torch.Tensor, q_pooled: torch.Tensor, img: torch.Tensor, nh: int) -> torch.Tensor:
+    """bf16 [N, H/2, W/2, nh*hd] = 8x8-window attention of the pooled queries (fp32 [N, H/2, W/2, nh*hd]) against
+    k | v = xn . W_kv^T + b_kv projected in the kernel; xn bf16 [N, H, W, dim] (see lsam_kv_window_attention_fwd)."""
+    _need_gpu(xn, q_pooled, img)
+    assert xn.dtype == torch.bfloat16 and xn.is_contiguous() and xn.dim() == 4
+    assert q_pooled.dtype == torch.float32 and q_pooled.is_contiguous() and q_pooled.dim() == 4
+    N, H, W, dim = xn.shape
+    q = q_pooled.shape[-1]
+    out = torch.empty(N, H // 2, W // 2, q, dtype=torch.bfloat16, device=xn.device)
+    check(lib().lsam_kv_window_attention_fwd(ptr(xn), dim, ptr(q_pooled), q, ptr(img), ptr(out), q, N, H, W, dim, nh, q // nh,
+                                             stream()))
+    return out
+
+
 # ---- SAM heads pieces (csrc/heads.hip) ---------------------------------------------------------------------------
 def add_rows(a: torch.Tensor, b: Optional[torch.Tensor], out_dtype: torch.dtype) -> torch.Tensor:
     """out[m] = a[m] + b[m % rows(b)] as out_dtype; a fp32 / bf16 [M, C] (row-major), b fp32 [R, C] or None (a cast)."""

@@ -185,6 +185,19 @@ int lsam_neck_conv_pack_split(const float* weight, int in_channels, int out_chan
 int lsam_neck_level_fwd_split(const float* x, const void* image, const float* bias, const float* top32, void* out, float* out32,
                               int N, int H, int W, int in_channels, int out_channels, lsam_stream_t stream);
 
+/* Attention half of a q-pool stage-entry block with 8x8 windows (MultiScaleAttention.forward, hieradet.py:56-81, with
+ * q = do_pool(q) :69-71; Hiera-B+ block 2: 112 -> 224 channels, 4 heads of 56) in one kernel per window: the k | v
+ * projection of the window's 64 LN1 rows and softmax(q k^T / sqrt(hd)) v for its 16 pooled queries.  k | v (the largest
+ * tensor of the trunk: 940 MB per 16-frame batch) never exist in memory.  xn bf16 [N*H*W][ldx] (norm1 output), q_pooled
+ * fp32 [N*(H/2)*(W/2)][ldq] = do_pool(q) as lsam_linear_maxpool2x2 produces it, out bf16 [N*(H/2)*(W/2)][ldo] in the
+ * reference's head-major channel order.  image: lsam_kv_window_attention_pack(qkv.weight [3*nh*hd][dim], qkv.bias).
+ * bf16, nh == 4, hd % 8 == 0 and <= 64, dim % 8 == 0 and <= 128, H and W multiples of 8 (image_bytes returns 0 otherwise). */
+size_t lsam_kv_window_attention_image_bytes(int dim, int nh, int hd);
+int lsam_kv_window_attention_pack(const float* qkv_w, const float* qkv_b, int dim, int nh, int hd, void* image,
+                                  lsam_stream_t stream);
+int lsam_kv_window_attention_fwd(const void* xn, int ldx, const float* q_pooled, int ldq, const void* image, void* out, int ldo,
+                                 int N, int H, int W, int dim, int nh, int hd, lsam_stream_t stream);
+
 /* ---- SAM prompt encoder / mask decoder pieces (SAM2Base._forward_sam_heads, sam2_base.py:257-413) that are not a
  * Linear or a LayerNorm.  See image_segmentation_amd/sam_heads.py for the composition. ---- */
 /* out[m][c] = (T_out)(a[m][c] + b[m % b_rows][c]); b nullable (then a dtype conversion).  `queries + query_pe`,

@@ -498,3 +498,35 @@ def test_fused_tail_block_rejects_unsupported(ops):
     with pytest.raises(LsamError):
         ops.tail_block_pack(rnd(d, d).cuda(), rnd(d).cuda(), rnd(d).cuda(), rnd(d).cuda(), rnd(4 * d, d).cuda(),
                             rnd(4 * d).cuda(), rnd(d, 4 * d).cuda(), rnd(d).cuda())
+
+
+@pytest.mark.parametrize("N,H,W,dim,hd", [(2, 16, 24, 112, 56), (1, 8, 8, 96, 64), (3, 32, 16, 128, 24)])
+def test_kv_window_attention_fused(N, H, W, dim, hd):
+    """q-pool stage-entry block, 8x8 windows (hieradet.py:56-81 with do_pool(q) :69-71): k | v projected inside the
+    attention kernel against a plain fp32 torch evaluation of the same block half from the same bf16 inputs."""
+    import torch.nn.functional as F
+    from image_segmentation_amd import ops
+    nh, q = 4, 4 * hd
+    g = torch.Generator().manual_seed(dim + hd)
+    xn = torch.randn(N, H, W, dim, generator=g).bfloat16()
+    w = (torch.randn(3 * q, dim, generator=g) / dim ** 0.5).bfloat16().float()
+    b = 0.2 * torch.randn(3 * q, generator=g)
+    x32 = xn.float()
+    qkv = x32 @ w.t() + b                                                   # [N, H, W, 3q]
+    qf, kf, vf = qkv[..., :q], qkv[..., q:2 * q].bfloat16().float(), qkv[..., 2 * q:].bfloat16().float()
+    qp = F.max_pool2d(qf.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).contiguous()   # do_pool(q)
+    def windows(t, ws):                                                      # [N, h, w, C] -> [N*nwin, ws*ws, nh, hd]
+        n, hh, ww, c = t.shape
+        t = t.view(n, hh // ws, ws, ww // ws, ws, nh, c // nh).permute(0, 1, 3, 2, 4, 5, 6)
+        return t.reshape(-1, ws * ws, nh, c // nh)
+    qw, kw, vw = windows(qp.bfloat16().float(), 4), windows(kf, 8), windows(vf, 8)
+    o = F.scaled_dot_product_attention(qw.transpose(1, 2), kw.transpose(1, 2), vw.transpose(1, 2))   # [B, nh, 16, hd]
+    o = o.transpose(1, 2).reshape(N, H // 8, W // 8, 4, 4, q).permute(0, 1, 3, 2, 4, 5).reshape(N, H // 2, W // 2, q)
+    img = ops.kv_window_attention_pack(w.cuda(), b.cuda(), nh)
+    got = ops.kv_window_attention_fwd(xn.cuda(), qp.cuda(), img, nh)
+    assert got.dtype == torch.bfloat16 and tuple(got.shape) == (N, H // 2, W // 2, q)
+    assert rel_err(got.float(), o) < 1e-2
+    # unsupported geometries are refused, not rerouted
+    from image_segmentation_amd._C import LsamError
+    with pytest.raises(LsamError):
+        ops.kv_window_attention_fwd(xn.cuda()[:, :, :W - 4].contiguous(), qp.cuda()[:, :, :W // 2 - 2].contiguous(), img, nh)

@@ -1,0 +1,38 @@
+"""Dev aid: per-launch (cfg, M, N, K, us, rate) of one config-1 step, from liblsam's live event records."""
+import ctypes as C, os, sys, types
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench as B
+from image_segmentation_amd import _C
+if os.environ.get("LSAM_LIB"):
+    _C.LIB_PATH = os.path.abspath(os.environ["LSAM_LIB"])
+from image_segmentation_amd.sam_heads import SAM2Base
+from image_segmentation_amd.synth import synth_frames_device
+dev = torch.device("cuda", 0)
+enc = B.build(dev)
+sam = SAM2Base(image_encoder=enc).to(dev)
+for n, p in sam.named_parameters():
+    if not n.startswith("image_encoder."):
+        p.requires_grad = False
+img = synth_frames_device(16, 1024, 0, dev)
+def step():
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = sam.forward_image(img)
+    B.fpn_loss(out).backward()
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+cap = 600
+_C.check(_C.lib().lsam_prof_arm(cap))
+step()
+torch.cuda.synchronize()
+ms = (C.c_float * cap)(); wk = (C.c_double * cap)(); cfg = (C.c_int * cap)(); mnk = (C.c_int * (3 * cap))()
+n = _C.lib().lsam_prof_read(cap, ms, wk, cfg, mnk)
+tot = 0.0
+for i in range(n):
+    us = ms[i] * 1e3
+    tot += us
+    unit = "TF/s" if cfg[i] >= 1000 else "GB/s"
+    rate = wk[i] / (ms[i] * 1e-3) / (1e12 if cfg[i] >= 1000 else 1e9)
+    print(f"{i:3d} cfg {cfg[i]:5d}  M {mnk[3*i]:8d} N {mnk[3*i+1]:6d} K {mnk[3*i+2]:6d}  {us:8.1f} us  {rate:8.1f} {unit}")
+print("total", tot)
