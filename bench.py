@@ -53,6 +53,7 @@ KERNEL_NAMES = {
     2227: ("gemm3 256x224 persistent bf16 GEMM, column-guarded (N % 224 != 0), fp32 out", "flop"),
     2112: ("gemm2 256x112-tile bf16 GEMM, bf16 out (N % 224 != 0)", "flop"),
     2113: ("gemm2 256x112-tile bf16 GEMM, fp32 out", "flop"),
+    2032: ("skinny32: streaming N = 32 product (LoRA u / t columns)", "flop"),
     2128: ("gemm_cfg 128-wide-tile bf16 GEMM (N % 112 != 0: Hiera-L widths, LoRA u columns)", "flop"),
     4128: ("gemm_cfg 128-wide-tile fp32 GEMM", "flop"),
     5000: ("global attention (attn2_fwd)", "flop"),

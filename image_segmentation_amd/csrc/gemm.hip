@@ -1083,6 +1083,84 @@ template <bool OUTF32, bool POOL = false, bool NGUARD = false> static int launch
     return LSAM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Skinny products out[M][32] = A[M][K] . W[32][K]^T (the LoRA u = xn . [A_q | A_v]^T and t = dqkv . [B_q | B_v] columns,
+// lora_qkv.py:104-105 and their adjoints): 2.8 GFLOP over an 88 MB operand is a streaming read, and a 128-wide tile
+// kernel runs it on 128 workgroups with three quarters of every tile empty (55 us).  Here a workgroup owns 16 rows, its
+// four waves split K, every operand fragment is a lane's own 16-byte global load (no LDS staging, no barrier in the
+// loop), and the four partial tiles meet in LDS once.  Swapped product: a lane ends with 4 consecutive outputs of one row.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void skinny32_kernel(const GemmArgs p) {
+    using frag = typename Tr<T>::frag;
+    constexpr int EPC = Tr<T>::EPC, CPF = Tr<T>::CPF, UNR = sizeof(T) == 2 ? 7 : 4;
+    __shared__ __attribute__((aligned(16))) float part[3][2][64][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, lr = lane & 15;
+    const int m0 = blockIdx.x * 16;
+    const T* __restrict__ A = static_cast<const T*>(p.A) + (size_t)min(m0 + lr, p.M - 1) * p.lda;   // clamped rows are never stored
+    const T* __restrict__ W0 = static_cast<const T*>(p.W) + (size_t)lr * p.ldw;
+    const T* __restrict__ W1 = W0 + (size_t)16 * p.ldw;
+    const int nks = (p.K + 31) / 32, per = (nks + 3) / 4;
+    const int ks0 = wave * per, ks1 = min(nks, ks0 + per);
+    auto ldf = [&](const T* row, int ks) -> frag {
+        const int k0 = 32 * ks + 8 * g;
+        uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
+        if (k0 < p.K) {
+            c0 = *reinterpret_cast<const uint4*>(row + k0);
+            if constexpr (CPF == 2) c1 = *reinterpret_cast<const uint4*>(row + k0 + EPC);
+        }
+        return make_frag(c0, c1, T{});
+    };
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    for (int ks = ks0; ks < ks1; ks += UNR) {
+        frag a[UNR], w0[UNR], w1[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {   // all loads of the group requested before the first product
+            const int k = min(ks + u, nks - 1);
+            a[u] = ldf(A, k);
+            w0[u] = ldf(W0, k);
+            w1[u] = ldf(W1, k);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (ks + u < ks1) {
+                mma16(w0[u], a[u], acc0);
+                mma16(w1[u], a[u], acc1);
+            }
+    }
+    if (wave > 0) {
+        *reinterpret_cast<f32x4*>(part[wave - 1][0][lane]) = acc0;
+        *reinterpret_cast<f32x4*>(part[wave - 1][1][lane]) = acc1;
+    }
+    __syncthreads();
+    if (wave == 0 && m0 + lr < p.M) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            acc0 += *reinterpret_cast<const f32x4*>(part[w][0][lane]);
+            acc1 += *reinterpret_cast<const f32x4*>(part[w][1][lane]);
+        }
+        // lane: row m0 + lr, columns 4 g .. 4 g + 3 (acc0) and 16 + 4 g .. (acc1)
+        if ((p.flags & LSAM_EPI_OUT_F32) || sizeof(T) == 4) {
+            float* o = static_cast<float*>(p.out) + (size_t)(m0 + lr) * p.ldo + 4 * g;
+            store4(o, acc0);
+            store4(o + 16, acc1);
+        } else {
+            T* o = static_cast<T*>(p.out) + (size_t)(m0 + lr) * p.ldo + 4 * g;
+            store4(o, acc0);
+            store4(o + 16, acc1);
+        }
+    }
+}
+
+template <typename T> static int launch_skinny32(const GemmArgs& a, hipStream_t s) {
+    const int rec = prof_begin(s);
+    hipLaunchKernelGGL(skinny32_kernel<T>, dim3(cdiv(a.M, 16)), dim3(256), 0, s, a);
+    LSAM_LAUNCH_CHECK();
+    prof_end(rec, s, 2.0 * a.M * a.N * a.K, (int)sizeof(T) * 1000 + 32, a.M, a.N, a.K);
+    return LSAM_OK;
+}
+
 // pooled epilogue: whole TH x TW patches (TW = min(W, 128) a multiple of 32, TH = 256 / TW), 224-wide column tiles
 bool gemm_pool_supported(int H, int W, int N) {
     if (H <= 0 || W <= 0 || W % 32 != 0 || N % 224 != 0) return false;
@@ -1172,6 +1250,9 @@ template <typename T> int launch_gemm(const GemmArgs& a, hipStream_t s) {
         return of32 ? launch_v2<T, 1, true>(a, s) : launch_v2<T, 1, sizeof(T) == 4>(a, s);
     }
     if (a.N % 112 == 0) return launch_cfg<T, 2, 7, 4, 1>(a, s);
+    // skinny outputs (the LoRA u = xn . A^T and t = dqkv . B products): a streaming kernel without LDS staging
+    if (a.N == 32 && a.M >= 1024 && !a.bias && !a.res && !a.aux && !a.out2 && (a.flags & ~LSAM_EPI_OUT_F32) == 0)
+        return launch_skinny32<T>(a, s);
     return launch_cfg<T, 4, 4, 2, 2>(a, s);
 }
 template int launch_gemm<float>(const GemmArgs&, hipStream_t);

@@ -530,3 +530,22 @@ def test_kv_window_attention_fused(N, H, W, dim, hd):
     from image_segmentation_amd._C import LsamError
     with pytest.raises(LsamError):
         ops.kv_window_attention_fwd(xn.cuda()[:, :, :W - 4].contiguous(), qp.cuda()[:, :, :W // 2 - 2].contiguous(), img, nh)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,K", [(16384, 896), (2000, 2688), (1030, 120), (1024, 40)])
+def test_linear_skinny32(dt, M, K):
+    """N = 32 products (the LoRA u / t columns) take the streaming kernel; written in place behind the operand's K columns,
+    as the plan does (xn[:, d:d+32] = xn[:, :d] . A^T)."""
+    from image_segmentation_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    buf = torch.randn(M, K + 32, generator=g).to(dt).cuda()
+    w = (torch.randn(32, K, generator=g) / K ** 0.5).to(dt).cuda()
+    a = buf[:, :K]
+    ref = a.double() @ w.double().t()
+    out = ops.linear(a, w, out=buf[:, K:])
+    assert out.data_ptr() == buf[:, K:].data_ptr()
+    assert rel_err(buf[:, K:].double(), ref) < (1e-6 if dt == torch.float32 else 5e-3)
+    assert torch.equal(buf[:, :K], a)                                   # the operand columns are untouched
+    o32 = ops.linear(a, w, out_f32=True)
+    assert o32.dtype == torch.float32 and rel_err(o32.double(), ref) < (1e-6 if dt == torch.float32 else 1e-5 + 0)
