@@ -403,14 +403,16 @@ int launch_outer_reduce(const T* X, int ldx, const T* Y, int ldy, int M, int C, 
     LSAM_LAUNCH_CHECK();
     return LSAM_OK;
 }
-// Four reductions of one LoRA block (dA_q, dB_q, dA_v, dB_v) in ONE partial + ONE final launch:
-// blockIdx.z selects the job.  Same arithmetic and summation order as four launch_outer_reduce calls
-// (bit-identical results); the point is four times the workgroups in flight for a latency-bound
-// kernel and two launches instead of eight.
-template <typename T>
+// Four reductions of one LoRA block (dA_q, dB_q, dA_v, dB_v) in ONE partial + ONE final launch: blockIdx.z selects the
+// job.  The point is four times the workgroups in flight for a latency-bound kernel and two launches instead of eight.
+// RQ = number of 4-column groups of Y that hold the rank (1 for r <= 4, the reference's setting): the columns beyond
+// are zero by construction and are neither multiplied nor written (4x less VALU work at r = 4, which is what bounded the
+// partial pass).  The final pass sums the chunk partials in a fixed order -- four interleaved slices per output, then the
+// slices -- so the result is deterministic (run-to-run bit-identical), though not the same rounding as the one-job kernels.
+template <typename T, int RQ>
 __global__ __launch_bounds__(64) void outer_partial4_kernel(const OuterJobs j, int M, int C, float* __restrict__ partial,
                                                             size_t job_stride) {
-    __shared__ float ys[OR_MCH][16];
+    __shared__ float ys[OR_MCH][4 * RQ];
     const int z = blockIdx.z;
     const T* __restrict__ X = static_cast<const T*>(j.X[z]);
     const T* __restrict__ Y = static_cast<const T*>(j.Y[z]);
@@ -418,8 +420,8 @@ __global__ __launch_bounds__(64) void outer_partial4_kernel(const OuterJobs j, i
     const int lane = threadIdx.x;
     const int m0 = blockIdx.y * OR_MCH;
     const int rows = min(OR_MCH, M - m0);
-    for (int i = lane; i < OR_MCH * 4; i += 64) {
-        const int r = i >> 2, q = i & 3;
+    for (int i = lane; i < OR_MCH * RQ; i += 64) {
+        const int r = i / RQ, q = i % RQ;
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (r < rows) v = load4(Y + (size_t)(m0 + r) * ldy + 4 * q);
         *reinterpret_cast<f32x4*>(&ys[r][4 * q]) = v;
@@ -427,13 +429,28 @@ __global__ __launch_bounds__(64) void outer_partial4_kernel(const OuterJobs j, i
     __syncthreads();
     const int c = (blockIdx.x * 64 + lane) * 4;
     if (c >= C) return;
-    f32x4 acc[16];
+    f32x4 acc[4 * RQ];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < rows; ++r) {
-        const f32x4 xv = load4(X + (size_t)(m0 + r) * ldx + c);
+    for (int k = 0; k < 4 * RQ; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const T* xp = X + (size_t)m0 * ldx + c;
+    int r = 0;
+    for (; r + 4 <= rows; r += 4) {   // four rows' loads in flight
+        f32x4 xv[4];
 #pragma unroll
-        for (int kq = 0; kq < 4; ++kq) {
+        for (int u = 0; u < 4; ++u) xv[u] = load4(xp + (size_t)(r + u) * ldx);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int kq = 0; kq < RQ; ++kq) {
+                const f32x4 yv = *reinterpret_cast<const f32x4*>(&ys[r + u][4 * kq]);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[4 * kq + jj] += xv[u] * yv[jj];
+            }
+    }
+    for (; r < rows; ++r) {
+        const f32x4 xv = load4(xp + (size_t)r * ldx);
+#pragma unroll
+        for (int kq = 0; kq < RQ; ++kq) {
             const f32x4 yv = *reinterpret_cast<const f32x4*>(&ys[r][4 * kq]);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) acc[4 * kq + jj] += xv * yv[jj];
@@ -443,7 +460,7 @@ __global__ __launch_bounds__(64) void outer_partial4_kernel(const OuterJobs j, i
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
-        for (int kq = 0; kq < 4; ++kq) {
+        for (int kq = 0; kq < RQ; ++kq) {
             f32x4 o;
             o[0] = acc[4 * kq + 0][jj]; o[1] = acc[4 * kq + 1][jj];
             o[2] = acc[4 * kq + 2][jj]; o[3] = acc[4 * kq + 3][jj];
@@ -451,16 +468,21 @@ __global__ __launch_bounds__(64) void outer_partial4_kernel(const OuterJobs j, i
         }
     }
 }
-__global__ void outer_final4_kernel(const OuterJobs j, const float* __restrict__ partial, size_t job_stride, int nch, int C,
-                                    int R) {
+// 64 outputs per workgroup; wave s of the four sums the chunks ch = s, s + 4, ...; the four slice sums meet in LDS
+__global__ __launch_bounds__(256) void outer_final4_kernel(const OuterJobs j, const float* __restrict__ partial, size_t job_stride,
+                                                           int nch, int C, int R) {
+    __shared__ float sl[4][64];
     const int z = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= C * R) return;
-    const int c = i / R, k = i % R;
-    const float* p = partial + z * job_stride;
+    const int o = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o;
+    const bool ok = i < C * R;
+    const int c = ok ? i / R : 0, k = ok ? i % R : 0;
+    const float* p = partial + z * job_stride + (size_t)c * 16 + k;
     float s = 0.f;
-    for (int ch = 0; ch < nch; ++ch) s += p[((size_t)ch * C + c) * 16 + k];
-    j.out[z][c * j.cs[z] + k * j.ks[z]] = s;
+    for (int ch = slice; ch < nch; ch += 4) s += p[(size_t)ch * C * 16];
+    sl[slice][o] = s;
+    __syncthreads();
+    if (slice == 0 && ok) j.out[z][c * j.cs[z] + k * j.ks[z]] = (sl[0][o] + sl[1][o]) + (sl[2][o] + sl[3][o]);
 }
 template <typename T> int launch_outer_reduce4(const OuterJobs& j, int M, int C, int R, void* partial, hipStream_t s) {
     LSAM_REQUIRE(partial && M > 0 && C > 0, LSAM_ERR_BAD_ARG, "outer_reduce4: null/empty");
@@ -471,10 +493,13 @@ template <typename T> int launch_outer_reduce4(const OuterJobs& j, int M, int C,
     const int nch = cdiv(M, OR_MCH);
     const size_t job_stride = (size_t)nch * C * 16;
     ProfScope ps(s, 4.0 * M * (C + 16) * sizeof(T), PROF_OUTER, M, C, R);
-    hipLaunchKernelGGL(outer_partial4_kernel<T>, dim3(cdiv(C, 256), nch, 4), dim3(64), 0, s, j, M, C,
-                       static_cast<float*>(partial), job_stride);
+    const dim3 grid(cdiv(C, 256), nch, 4);
+    float* pp = static_cast<float*>(partial);
+    if (R <= 4) hipLaunchKernelGGL((outer_partial4_kernel<T, 1>), grid, dim3(64), 0, s, j, M, C, pp, job_stride);
+    else if (R <= 8) hipLaunchKernelGGL((outer_partial4_kernel<T, 2>), grid, dim3(64), 0, s, j, M, C, pp, job_stride);
+    else hipLaunchKernelGGL((outer_partial4_kernel<T, 4>), grid, dim3(64), 0, s, j, M, C, pp, job_stride);
     LSAM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(outer_final4_kernel, dim3(cdiv(C * R, 256), 4), dim3(256), 0, s, j, static_cast<const float*>(partial),
+    hipLaunchKernelGGL(outer_final4_kernel, dim3(cdiv(C * R, 64), 4), dim3(256), 0, s, j, static_cast<const float*>(partial),
                        job_stride, nch, C, R);
     LSAM_LAUNCH_CHECK();
     return LSAM_OK;
