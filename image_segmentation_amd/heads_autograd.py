@@ -1,0 +1,230 @@
+"""Autograd nodes of the SAM heads (image_segmentation_amd/sam_heads.py) and of the mask losses: every forward is one
+liblsam call (or a short fixed sequence), every backward is input-gradient-only HIP work -- `lsam_linear` on packed
+transposed weights, `lsam_layernorm_bwd`, and the kernels of csrc/heads_bwd.hip.  The heads are frozen
+(train_lora_sam.py:116-117), so there are no weight-gradient GEMMs; the only parameter gradients are those of the
+decoder-side LoRA factors (lora_qkv.py:11-67), formed by `lsam_outer_reduce` over the (few) token rows.
+
+Shapes are 2-D row-major unless stated; "T" is the heads' operand dtype (fp32 by default, bf16 optionally); token and
+image streams, and all gradients of fp32 tensors, are fp32.  torch itself only slices, concatenates and indexes."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+
+
+def _f32(g: torch.Tensor) -> torch.Tensor:
+    """fp32 contiguous copy of a gradient (a cast kernel when it arrives in T)."""
+    if g.dtype == torch.float32:
+        return g if g.is_contiguous() else g.contiguous()
+    g = g.contiguous()
+    return ops.add_rows(g.view(-1, g.shape[-1]), None, torch.float32).view(g.shape)
+
+
+def _as(g32: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    if dtype == torch.float32:
+        return g32
+    return ops.add_rows(g32.view(-1, g32.shape[-1]), None, dtype).view(g32.shape)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x @ W^T + b) (+ res): x T [M, K], packed W T [Npad, Kpad], fp32 bias, fp32 res [M, Npad]; returns [M, Npad]
+    (fp32 with out_f32, else T).  `w_param` is the module's weight when it is trainable (a LoRA factor), else None."""
+
+    @staticmethod
+    def forward(ctx, x, res, w_param, pack, relu, sigmoid, out_f32):
+        w, b, wT, n = pack
+        y = ops.linear(x, w, b, res=res, K=x.shape[1], relu=relu, sigmoid=sigmoid, out_f32=out_f32)
+        ctx.pack, ctx.relu, ctx.sigmoid, ctx.has_res = pack, relu, sigmoid, res is not None
+        ctx.x_dtype, ctx.k = x.dtype, x.shape[1]
+        need_w = w_param is not None and w_param.requires_grad
+        ctx.save_for_backward(y if (relu or sigmoid) else None, x if need_w else None)
+        ctx.w_shape = tuple(w_param.shape) if need_w else None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        w, b, wT, n = ctx.pack
+        y, x = ctx.saved_tensors
+        g32 = _f32(g)
+        d_res = g32 if (ctx.has_res and ctx.needs_input_grad[1]) else None
+        if ctx.has_res and (ctx.relu or ctx.sigmoid):
+            raise RuntimeError("LinearFn: residual with an activation is not used by the heads")
+        if ctx.relu or ctx.sigmoid:
+            g32 = ops.act_bwd(g32, y, 0 if ctx.relu else 1)
+        gT = _as(g32, w.dtype)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear(gT, wT, K=gT.shape[1], out_f32=ctx.x_dtype == torch.float32)      # dY . W, [M, Kpad]
+            if dx.shape[1] != ctx.k:
+                dx = dx[:, :ctx.k].contiguous()
+        dw = None
+        if ctx.w_shape is not None and ctx.needs_input_grad[2]:
+            nw, kw = ctx.w_shape
+            # dW[n][k] = sum_m g[m][n] x[m][k]: the reduction runs over the side with <= 16 columns (the LoRA rank)
+            if nw <= 16:
+                y16 = torch.zeros(gT.shape[0], 16, dtype=gT.dtype, device=gT.device)
+                y16[:, :min(16, gT.shape[1])] = gT[:, :16]
+                dw = ops.outer_reduce(x[:, :kw].contiguous(), y16, nw, transpose_out=True)       # [nw, kw]
+            elif kw <= 16:
+                x16 = torch.zeros(x.shape[0], 16, dtype=x.dtype, device=x.device)
+                x16[:, :min(16, x.shape[1])] = x[:, :16]
+                dw = ops.outer_reduce(gT[:, :nw].contiguous(), x16, kw, transpose_out=False)     # [nw, kw]
+            else:
+                raise RuntimeError("LinearFn: weight gradients exist for rank <= 16 LoRA factors only")
+        return dx, d_res, dw, None, None, None, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dim of fp32 rows, frozen affine parameters; fp32 out."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        if ctx.needs_input_grad[0]:
+            y, stats = ops.layernorm_fwd(x, weight, bias, torch.float32, want_stats=True, eps=eps)
+            ctx.save_for_backward(x, stats, weight)
+        else:
+            y = ops.layernorm_fwd(x, weight, bias, torch.float32, eps=eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, stats, weight = ctx.saved_tensors
+        dx, _ = ops.layernorm_bwd(_f32(g), x, stats, weight, None, torch.float32)
+        return dx, None, None, None
+
+
+class AddRowsFn(torch.autograd.Function):
+    """out[m] = a[m] + b[m % rows(b)] as `dtype` (b None: a cast).  b gets a gradient only when it has one row per row of a."""
+
+    @staticmethod
+    def forward(ctx, a, b, dtype):
+        ctx.a_dtype = a.dtype
+        ctx.b_full = b is not None and b.shape[0] == a.shape[0]
+        return ops.add_rows(a, b, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        g32 = _f32(g)
+        da = _as(g32, ctx.a_dtype) if ctx.needs_input_grad[0] else None
+        db = None
+        if ctx.needs_input_grad[1]:
+            if not ctx.b_full:
+                raise RuntimeError("AddRowsFn: a broadcast addend is a frozen embedding in the heads; it has no gradient path")
+            db = g32
+        return da, db, None
+
+
+class MhaFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(hd)) v for contiguous T [B, n, C] operands."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, nh):
+        out = ops.mha(q, k, v, nh)
+        ctx.nh = nh
+        ctx.save_for_backward(q, k, v, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v, out = ctx.saved_tensors
+        dq, dk, dv = ops.mha_bwd(q, k, v, out, _f32(g), ctx.nh)
+        return _as(dq, q.dtype), _as(dk, k.dtype), _as(dv, v.dtype), None
+
+
+class Upscale2x2Fn(torch.autograd.Function):
+    """T [B, 2H, 2W, C] = GELU(LN2d?(pixel_shuffle(g) + skip)); gradient to g only (the skip comes from LoRA-free stages)."""
+
+    @staticmethod
+    def forward(ctx, g, skip, lnw, lnb, eps, B, H, W, C, dtype):
+        ln = (lnw, lnb) if lnw is not None else None
+        ctx.save_for_backward(g, skip, lnw, lnb)
+        ctx.cfg = (eps, B, H, W, C, dtype)
+        return ops.upscale2x2(g, skip, ln, eps, B, H, W, C, dtype)
+
+    @staticmethod
+    def backward(ctx, go):
+        g, skip, lnw, lnb = ctx.saved_tensors
+        eps, B, H, W, C, dtype = ctx.cfg
+        dg = ops.upscale2x2_bwd(_f32(go), g, skip, (lnw, lnb) if lnw is not None else None, eps, B, H, W, C, dtype)
+        return (dg,) + (None,) * 9
+
+
+class MaskProductFn(torch.autograd.Function):
+    """logits[b] = up[b] @ hyper[b]^T (mask_decoder.py:238-239): up T [B, HW, C], hyper T [B, L, C] -> fp32 [B, HW, L]."""
+
+    @staticmethod
+    def forward(ctx, up, hyper):
+        B, HW, C = up.shape
+        L = hyper.shape[1]
+        logits = torch.empty(B, HW, L, dtype=torch.float32, device=up.device)
+        for b in range(B):
+            ops.linear(up[b], hyper[b], out_f32=True, out=logits[b])
+        ctx.save_for_backward(up, hyper)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        up, hyper = ctx.saved_tensors
+        B, HW, C = up.shape
+        L = hyper.shape[1]
+        g32 = _f32(g)
+        gT = _as(g32.view(B * HW, L), up.dtype).view(B, HW, L)
+        d_up = d_hy = None
+        if ctx.needs_input_grad[0]:
+            d_up = torch.empty(B, HW, C, dtype=up.dtype, device=up.device)
+            hT = hyper.transpose(1, 2).contiguous()                                   # [B, C, L]: index plumbing
+            for b in range(B):
+                ops.linear(gT[b], hT[b], out=d_up[b])
+        if ctx.needs_input_grad[1]:
+            g16 = torch.zeros(B, HW, 16, dtype=up.dtype, device=up.device)
+            g16[:, :, :L] = gT
+            d_hy = torch.stack([ops.outer_reduce(up[b], g16[b], L, transpose_out=True) for b in range(B)], 0)   # fp32 [B, L, C]
+            d_hy = _as(d_hy.view(B * L, C), hyper.dtype).view(B, L, C)
+        return d_up, d_hy
+
+
+class MaskGateFn(torch.autograd.Function):
+    """fp32 [B, n_masks, HW] = columns first.. of logits [B, HW, L], NO_OBJ_SCORE where the object score is <= 0."""
+
+    @staticmethod
+    def forward(ctx, logits, obj, first, n_masks, no_obj):
+        ctx.save_for_backward(obj)
+        ctx.cfg = (first, logits.shape[2])
+        return ops.mask_gate(logits, obj, first, n_masks, no_obj)
+
+    @staticmethod
+    def backward(ctx, g):
+        (obj,) = ctx.saved_tensors
+        first, L = ctx.cfg
+        return ops.mask_gate_bwd(_f32(g), obj, first, L), None, None, None, None
+
+
+class BilinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return ops.bilinear_upsample(x, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.bilinear_upsample_bwd(_f32(g), ctx.scale), None
+
+
+class MaskLossSumsFn(torch.autograd.Function):
+    """fp32 [N, M, 6] per-candidate sums of the mask losses (lsam_mask_loss_sums); gradient to the logits only."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, alpha, gamma):
+        ctx.save_for_backward(logits, targets)
+        ctx.cfg = (alpha, gamma)
+        return ops.mask_loss_sums(logits, targets, alpha, gamma)
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, targets = ctx.saved_tensors
+        alpha, gamma = ctx.cfg
+        coef = g[..., :3].contiguous()
+        return ops.mask_loss_bwd(logits, targets, coef, alpha, gamma).view(logits.shape), None, None, None

@@ -551,3 +551,88 @@ def bilinear_upsample(x: torch.Tensor, scale: int) -> torch.Tensor:
     out = torch.empty(B, Cc, H * scale, W * scale, dtype=torch.float32, device=x.device)
     check(lib().lsam_bilinear_upsample(ptr(x), ptr(out), B * Cc, H, W, scale, stream()))
     return out
+
+
+# ---- input gradients of the SAM heads, mask-loss sums (csrc/heads_bwd.hip) -------------------------------------------
+def act_bwd(dy: torch.Tensor, y: torch.Tensor, kind: int) -> torch.Tensor:
+    """fp32 dx = dy * act'(.) from the activation's output y (kind 0 ReLU, 1 sigmoid); same shape, contiguous."""
+    _need_gpu(dy, y)
+    dy = _f32c(dy)
+    y = y.detach().contiguous()
+    assert dy.shape == y.shape and dy.numel() % 4 == 0
+    dx = torch.empty_like(dy)
+    check(lib().lsam_act_bwd(kind, ptr(dy), dtype_code(y.dtype), ptr(y), ptr(dx), dy.numel(), stream()))
+    return dx
+
+
+def mha_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, nh: int):
+    """(dq, dk, dv) fp32 of ops.mha for contiguous [B, n, C] operands."""
+    _need_gpu(q, k, v, out, dout)
+    q, k, v, out = q.detach().contiguous(), k.detach().contiguous(), v.detach().contiguous(), out.detach().contiguous()
+    dout = _f32c(dout)
+    B, nq, Cc = q.shape
+    nk = k.shape[1]
+    dq = torch.empty(B, nq, Cc, dtype=torch.float32, device=q.device)
+    dk = torch.empty(B, nk, Cc, dtype=torch.float32, device=q.device)
+    dv = torch.empty(B, nk, Cc, dtype=torch.float32, device=q.device)
+    check(lib().lsam_mha_bwd(dtype_code(q.dtype), ptr(q), ptr(k), ptr(v), ptr(out), ptr(dout), ptr(dq), ptr(dk), ptr(dv), B, nq, nk,
+                             nh, Cc // nh, stream()))
+    return dq, dk, dv
+
+
+def upscale2x2_bwd(dout: torch.Tensor, g: torch.Tensor, skip: Optional[torch.Tensor],
+                   ln: Optional[Tuple[torch.Tensor, torch.Tensor]], eps: float, B: int, H: int, W: int, Cc: int,
+                   dtype: torch.dtype) -> torch.Tensor:
+    """fp32 d_g [B*H*W, 4C] of ops.upscale2x2 (dout [B, 2H, 2W, C])."""
+    _need_gpu(dout, g, skip)
+    dout = _f32c(dout)
+    assert g.dtype == torch.float32 and g.is_contiguous() and dout.numel() == B * 4 * H * W * Cc
+    if skip is not None:
+        assert skip.dtype == dtype and skip.is_contiguous()
+    w, b = (_f32c(ln[0]), _f32c(ln[1])) if ln is not None else (None, None)
+    dg = torch.empty_like(g)
+    check(lib().lsam_upscale2x2_bwd(dtype_code(dtype), ptr(dout), ptr(g), ptr(skip), ptr(w), ptr(b), eps, ptr(dg), B, H, W, Cc,
+                                    stream()))
+    return dg
+
+
+def mask_gate_bwd(d_masks: torch.Tensor, obj: Optional[torch.Tensor], first: int, L: int) -> torch.Tensor:
+    """fp32 d_logits [B, HW, L] from d_masks fp32 [B, n_masks, HW]."""
+    _need_gpu(d_masks, obj)
+    d_masks = _f32c(d_masks)
+    B, nm, HW = d_masks.shape
+    o = _f32c(obj.reshape(-1)) if obj is not None else None
+    out = torch.empty(B, HW, L, dtype=torch.float32, device=d_masks.device)
+    check(lib().lsam_mask_gate_bwd(ptr(d_masks), ptr(o), ptr(out), L, B, HW, first, nm, stream()))
+    return out
+
+
+def bilinear_upsample_bwd(dout: torch.Tensor, scale: int) -> torch.Tensor:
+    _need_gpu(dout)
+    dout = _f32c(dout)
+    B, Cc, Ho, Wo = dout.shape
+    din = torch.empty(B, Cc, Ho // scale, Wo // scale, dtype=torch.float32, device=dout.device)
+    check(lib().lsam_bilinear_upsample_bwd(ptr(dout), ptr(din), B * Cc, Ho // scale, Wo // scale, scale, stream()))
+    return din
+
+
+def mask_loss_sums(logits: torch.Tensor, targets: torch.Tensor, alpha: float, gamma: float) -> torch.Tensor:
+    """fp32 [N, M, 6] per-candidate sums of the mask losses (see lsam_mask_loss_sums); logits [N, M, H, W], targets [N, H, W]."""
+    _need_gpu(logits, targets)
+    x, t = _f32c(logits), _f32c(targets)
+    N, M = x.shape[:2]
+    HW = x[0, 0].numel()
+    assert t.numel() == N * HW
+    sums = torch.empty(N, M, 6, dtype=torch.float32, device=x.device)
+    check(lib().lsam_mask_loss_sums(ptr(x), ptr(t), ptr(sums), N, M, HW, alpha, gamma, stream()))
+    return sums
+
+
+def mask_loss_bwd(logits: torch.Tensor, targets: torch.Tensor, coef: torch.Tensor, alpha: float, gamma: float) -> torch.Tensor:
+    _need_gpu(logits, targets, coef)
+    x, t, c = _f32c(logits), _f32c(targets), _f32c(coef)
+    N, M = x.shape[:2]
+    HW = x[0, 0].numel()
+    dx = torch.empty_like(x)
+    check(lib().lsam_mask_loss_bwd(ptr(x), ptr(t), ptr(c), ptr(dx), N, M, HW, alpha, gamma, stream()))
+    return dx

@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from . import heads_autograd as HA
 from ._C import LsamError
 from .hieradet import MLP, _compute_dtype
 from .image_encoder import forward_image as _forward_image
@@ -228,7 +229,8 @@ class _PackCache:
         return e[1]
 
     def linear(self, mod: nn.Module, dt, weight2d=None, bias=None, name=None):
-        """(packed T weight [pad8(N), K], fp32 bias [pad8(N)] or None, N) of a Linear-like module."""
+        """(packed T weight [pad8(N), pad8(K)], fp32 bias [pad8(N)] or None, its packed transpose [pad8(K), pad8(N)] for the
+        input gradient, N) of a Linear-like module."""
         params = [p for p in (mod.weight, getattr(mod, "bias", None)) if p is not None]
 
         def build():
@@ -242,7 +244,7 @@ class _PackCache:
             if b is not None:
                 bp = torch.zeros(_pad8(n), dtype=torch.float32, device=w2.device)
                 bp[:n] = b.detach().float().reshape(-1)
-            return ops.pack_matrix(wp, dt), bp, n
+            return ops.pack_matrix(wp, dt), bp, ops.pack_matrix(wp.t(), dt), n
 
         return self.get((id(mod), name), params, dt, build)
 
@@ -291,12 +293,17 @@ class SAM2Base(nn.Module):
     def _lin(self, x, mod, dt, weight2d=None, bias=None, name=None, keep_pad=False, **kw):
         """x T [M, K] -> [M, N] through mod's packed weight (N, K zero-padded to multiples of 8; `keep_pad` returns the
         padded columns, all zero, for a following product over them)."""
-        w, b, n = self._packs.linear(mod, dt, weight2d, bias, name)
-        out = ops.linear(x, w, b, K=x.shape[1], **kw)
+        pack = self._packs.linear(mod, dt, weight2d, bias, name)
+        wp = mod.weight if (weight2d is None and mod.weight.requires_grad) else None      # a trainable LoRA factor
+        out = HA.LinearFn.apply(x, kw.get("res"), wp, pack, kw.get("relu", False), kw.get("sigmoid", False), kw.get("out_f32", False))
+        n = pack[3]
         return out if keep_pad or out.shape[1] == n else out[:, :n]
 
     def _T(self, x, dt):
-        return x if x.dtype == dt else ops.add_rows(x, None, dt)
+        return x if x.dtype == dt else HA.AddRowsFn.apply(x, None, dt)
+
+    def _add(self, a, b, dt):
+        return HA.AddRowsFn.apply(a, b, dt)
 
     def _mlp(self, mlp: MLP, x, dt):
         """sam2_utils.MLP: Linear + ReLU ... Linear (+ sigmoid); x T [M, in] -> fp32 [M, out]."""
@@ -320,11 +327,11 @@ class SAM2Base(nn.Module):
         kh = self._lin(k, att.k_proj, dt)
         vh = self._lin(v, att.v_proj, dt, res=tv)
         c = att.internal_dim
-        o = ops.mha(qh.view(B, -1, c), kh.view(B, -1, c), vh.view(B, -1, c), att.num_heads)
+        o = HA.MhaFn.apply(qh.reshape(B, -1, c), kh.reshape(B, -1, c), vh.reshape(B, -1, c), att.num_heads)
         return self._lin(o.view(-1, c), att.out_proj, dt, res=residual, out_f32=True)
 
     def _ln(self, norm: nn.LayerNorm, x):
-        return ops.layernorm_fwd(x, norm.weight, norm.bias, torch.float32, eps=norm.eps)
+        return HA.LayerNormFn.apply(x, norm.weight.detach(), norm.bias.detach(), norm.eps)
 
     def get_dense_pe(self, device) -> torch.Tensor:
         """PromptEncoder.get_dense_pe (prompt_encoder.py:63-72) as fp32 rows [E*E, D]; constant per model, cached."""
@@ -354,7 +361,6 @@ class SAM2Base(nn.Module):
         return ops.add_rows(enc, table[idx].contiguous(), torch.float32).view(B, P + 1, -1)
 
     # -- sam/transformer.py:60-108 + mask_decoder.py:161-250 --------------------------------------------------------------
-    @torch.no_grad()
     def _predict_masks(self, pix: torch.Tensor, sparse: torch.Tensor, feat_s0: torch.Tensor, feat_s1: torch.Tensor):
         """pix: image embedding rows [B*E*E, D] (fp32 or T), sparse fp32 [B, P+1, D], feat_s0 / feat_s1 NHWC
         [B, 4E, 4E, D/8] / [B, 2E, 2E, D/4].  Returns (mask logits fp32 [B, (4E)^2, 8], iou fp32 [B, 4], obj fp32 [B, 1])."""
@@ -369,28 +375,28 @@ class SAM2Base(nn.Module):
         point_embedding = tokens.view(B * Nt, D)
         queries = point_embedding
         key_pe = self.get_dense_pe(dev)                                                                 # [E*E, D]
-        keys = ops.add_rows(pix, self.sam_prompt_encoder.no_mask_embed.weight.detach().float(), torch.float32)   # src = emb + dense
+        keys = self._add(pix, self.sam_prompt_encoder.no_mask_embed.weight.detach().float(), torch.float32)   # src = emb + dense
 
         for l, blk in enumerate(tr.layers):
             if blk.skip_first_layer_pe:
                 qT = self._T(queries, dt)
                 queries = self._attention(blk.self_attn, qT, qT, qT, B, dt)
             else:
-                q = ops.add_rows(queries, point_embedding, dt)
+                q = self._add(queries, point_embedding, dt)
                 queries = self._attention(blk.self_attn, q, q, self._T(queries, dt), B, dt, residual=queries)
             queries = self._ln(blk.norm1, queries)
-            q = ops.add_rows(queries, point_embedding, dt)
-            k = ops.add_rows(keys, key_pe, dt)
+            q = self._add(queries, point_embedding, dt)
+            k = self._add(keys, key_pe, dt)
             queries = self._attention(blk.cross_attn_token_to_image, q, k, self._T(keys, dt), B, dt, residual=queries)
             queries = self._ln(blk.norm2, queries)
             h = self._lin(self._T(queries, dt), blk.mlp.layers[0], dt, relu=True)
             queries = self._lin(h, blk.mlp.layers[1], dt, res=queries, out_f32=True)
             queries = self._ln(blk.norm3, queries)
-            q = ops.add_rows(queries, point_embedding, dt)
+            q = self._add(queries, point_embedding, dt)
             keys = self._attention(blk.cross_attn_image_to_token, k, q, self._T(queries, dt), B, dt, residual=keys)
             keys = self._ln(blk.norm4, keys)
-        q = ops.add_rows(queries, point_embedding, dt)
-        k = ops.add_rows(keys, key_pe, dt)
+        q = self._add(queries, point_embedding, dt)
+        k = self._add(keys, key_pe, dt)
         queries = self._attention(tr.final_attn_token_to_image, q, k, self._T(keys, dt), B, dt, residual=queries)
         hs = self._ln(tr.norm_final_attn, queries).view(B, Nt, D)
 
@@ -399,24 +405,20 @@ class SAM2Base(nn.Module):
         c1, c2 = up0.out_channels, up3.out_channels
         g1 = self._lin(self._T(keys, dt), up0, dt, weight2d=lambda: up0.weight.permute(2, 3, 1, 0).reshape(4 * c1, -1),
                        bias=lambda: up0.bias.repeat(4), name="ct", out_f32=True)
-        u1 = ops.upscale2x2(g1, feat_s1.to(dt).contiguous() if feat_s1.dtype != dt else feat_s1.contiguous(),
-                            (ln1.weight, ln1.bias), ln1.eps, B, E, E, c1, dt)
+        skip1 = (feat_s1.to(dt) if feat_s1.dtype != dt else feat_s1).detach().contiguous()   # LoRA-free stages: no gradient path
+        skip0 = (feat_s0.to(dt) if feat_s0.dtype != dt else feat_s0).detach().contiguous()
+        u1 = HA.Upscale2x2Fn.apply(g1.contiguous(), skip1, ln1.weight.detach(), ln1.bias.detach(), ln1.eps, B, E, E, c1, dt)
         g2 = self._lin(u1.view(-1, c1), up3, dt, weight2d=lambda: up3.weight.permute(2, 3, 1, 0).reshape(4 * c2, -1),
                        bias=lambda: up3.bias.repeat(4), name="ct", out_f32=True)
-        u2 = ops.upscale2x2(g2, feat_s0.to(dt).contiguous() if feat_s0.dtype != dt else feat_s0.contiguous(), None, 0.0,
-                            B, 2 * E, 2 * E, c2, dt)
+        u2 = HA.Upscale2x2Fn.apply(g2.contiguous(), skip0, None, None, 0.0, B, 2 * E, 2 * E, c2, dt)
         # ---- hyper-networks, IoU and object-score heads ----------------------------------------------------------------------
         nm = dec.num_mask_tokens
         hsT = self._T(hs.reshape(B * Nt, D), dt).view(B, Nt, D)
-        hyper = torch.zeros(B, 8, c2, dtype=torch.float32, device=dev)
-        for i in range(nm):
-            hyper[:, i] = self._mlp(dec.output_hypernetworks_mlps[i], hsT[:, 2 + i].contiguous(), dt)   # placement only
-        hyperT = self._T(hyper.view(B * 8, c2), dt).view(B, 8, c2)
+        hyper = torch.stack([self._mlp(dec.output_hypernetworks_mlps[i], hsT[:, 2 + i].contiguous(), dt) for i in range(nm)]
+                            + [torch.zeros(B, c2, dtype=torch.float32, device=dev)] * (8 - nm), dim=1)   # placement only: [B, 8, c2]
+        hyperT = self._T(hyper.reshape(B * 8, c2), dt).view(B, 8, c2)
         HW = 16 * E * E
-        logits = torch.empty(B, HW, 8, dtype=torch.float32, device=dev)
-        u2r = u2.view(B, HW, c2)
-        for b in range(B):                       # masks[b] = hyper_in[b] @ upscaled[b]  (mask_decoder.py:238-239)
-            ops.linear(u2r[b], hyperT[b], out_f32=True, out=logits[b])
+        logits = HA.MaskProductFn.apply(u2.view(B, HW, c2), hyperT)   # masks[b] = hyper_in[b] @ upscaled[b]  (mask_decoder.py:238-239)
         iou = self._mlp(dec.iou_prediction_head, hsT[:, 1].contiguous(), dt)
         if self.pred_obj_scores:
             head = dec.pred_obj_score_head
@@ -427,7 +429,6 @@ class SAM2Base(nn.Module):
         return logits, iou.contiguous(), obj.contiguous()
 
     # -- sam2_base.py:257-413 ----------------------------------------------------------------------------------------------
-    @torch.no_grad()
     def _forward_sam_heads(self, backbone_features: torch.Tensor, point_inputs=None, mask_inputs=None,
                            high_res_features: Optional[List[torch.Tensor]] = None, multimask_output: bool = False):
         """Same arguments and return tuple as the reference (obj_ptr is None: object pointers belong to the memory path).
@@ -453,8 +454,8 @@ class SAM2Base(nn.Module):
         pix = nhwc(backbone_features).view(B * E * E, D)
         logits, iou, obj = self._predict_masks(pix, sparse, nhwc(high_res_features[0]), nhwc(high_res_features[1]))
         first, nm = (1, 3) if multimask_output else (0, 1)
-        low = ops.mask_gate(logits, obj if self.pred_obj_scores else None, first, nm, NO_OBJ_SCORE).view(B, nm, 4 * E, 4 * E)
-        high = ops.bilinear_upsample(low, self.image_size // (4 * E))
+        low = HA.MaskGateFn.apply(logits, obj.detach() if self.pred_obj_scores else None, first, nm, NO_OBJ_SCORE).view(B, nm, 4 * E, 4 * E)
+        high = HA.BilinearFn.apply(low, self.image_size // (4 * E))
         ious = iou[:, first:first + nm]
         if multimask_output:
             best = torch.argmax(ious, dim=-1)                    # index selection
@@ -464,14 +465,13 @@ class SAM2Base(nn.Module):
             low_best, high_best = low, high
         return low, high, ious, low_best, high_best, None, obj
 
-    @torch.no_grad()
     def forward_first_frame(self, backbone_out: dict, point_coords: torch.Tensor, point_labels: torch.Tensor) -> dict:
         """A click on an initial frame: `_prepare_memory_conditioned_features` with no memory (`+ no_mem_embed`,
         sam2_base.py:669-674) and `_forward_sam_heads(multimask_output=True)` (the first click, sam2_base.py:797-812)."""
         f0, f1, f2 = backbone_out["backbone_fpn"]
         B, D, E, _ = f2.shape
         rows = f2.permute(0, 2, 3, 1).contiguous().view(B * E * E, D)
-        pix = ops.add_rows(rows, self.no_mem_embed.detach().float().view(1, D), torch.float32)
+        pix = self._add(rows, self.no_mem_embed.detach().float().view(1, D), torch.float32)
         pix = pix.view(B, E, E, D).permute(0, 3, 1, 2)
         low, high, ious, low_best, high_best, _, obj = self._forward_sam_heads(
             pix, {"point_coords": point_coords, "point_labels": point_labels}, None, [f0, f1], multimask_output=True)

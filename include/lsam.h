@@ -223,6 +223,36 @@ int lsam_mask_gate(const float* logits, int ldl, const float* obj_score, float* 
 /* F.interpolate(x, scale_factor=scale, mode="bilinear", align_corners=False) on fp32 [BC][H][W] (sam2_base.py:372-377). */
 int lsam_bilinear_upsample(const float* in, float* out, int BC, int H, int W, int scale, lsam_stream_t stream);
 
+/* ---- input gradients of the SAM heads and the mask losses.  The heads' weights are frozen (train_lora_sam.py:116-117), so --
+ * as in the trunk -- there are no weight-gradient GEMMs: Linear / ConvTranspose2d backward is lsam_linear on packed
+ * transposed weights, LayerNorm backward is lsam_layernorm_bwd, and the decoder-side LoRA factors (lora_qkv.py:11-67) get
+ * their gradients from lsam_outer_reduce.  These are the remaining pieces (autograd of sam/transformer.py:233-265,
+ * mask_decoder.py:161-250, sam2_base.py:359-380).  All fp32 gradients, deterministic (no atomics). */
+/* dx = dy * act'(.) computed from the activation's OUTPUT y (T): kind 0 = ReLU, 1 = sigmoid.  n % 4 == 0. */
+int lsam_act_bwd(int kind, const float* dy, int y_dtype, const void* y, float* dx, long n, lsam_stream_t stream);
+/* Backward of lsam_mha_fwd on contiguous [B][n][nh*hd] operands (q, k, v, out: T; dout, dq, dk, dv: fp32).
+ * hd in {16, 32}; min(nq, nk) <= 16 (the two-way transformer's shapes: 8 x 8, 8 x 4096, 4096 x 8). */
+int lsam_mha_bwd(int dtype, const void* q, const void* k, const void* v, const void* out, const float* dout, float* dq, float* dk,
+                 float* dv, int B, int nq, int nk, int nh, int hd, lsam_stream_t stream);
+/* Backward of lsam_upscale2x2_fwd with respect to g (fp32 [B*H*W][4*C]); dout fp32 [B][2H][2W][C]; the pre-activation is
+ * recomputed from g (+ skip, T, nullable).  The skip connection gets no gradient (it comes from frozen, LoRA-free stages). */
+int lsam_upscale2x2_bwd(int dtype, const float* dout, const float* g, const void* skip, const float* ln_w, const float* ln_b, float eps,
+                        float* dg, int B, int H, int W, int C, lsam_stream_t stream);
+/* Adjoints of lsam_mask_gate (d_logits fp32 [B][HW][ldl], zero outside the selected columns and for gated frames) and of
+ * lsam_bilinear_upsample. */
+int lsam_mask_gate_bwd(const float* d_masks, const float* obj_score, float* d_logits, int ldl, int B, int HW, int first, int n_masks,
+                       lsam_stream_t stream);
+int lsam_bilinear_upsample_bwd(const float* dout, float* din, int BC, int H, int W, int scale, lsam_stream_t stream);
+/* Mask losses (training/loss_fns.py:19-129): one pass over logits fp32 [N][M][HW] and targets fp32 [N][HW] (broadcast over
+ * the M candidates, :240) gives sums fp32 [N][M][6] = { sum sigmoid_focal_loss elements (alpha, gamma; alpha < 0: no alpha
+ * weighting), sum p t, sum p, sum t, |x > 0 and t > 0|, |x > 0 or t > 0| }, from which the focal mean, the dice ratio and the
+ * actual IoU of every candidate follow.  lsam_mask_loss_bwd takes coef fp32 [N][M][3] = d loss / d sums[., 0..2] and writes
+ * d_logits = coef0 focal'(x) + (coef1 t + coef2) p (1 - p)  (zeros for candidates whose coefficients are all zero). */
+int lsam_mask_loss_sums(const float* logits, const float* targets, float* sums, int N, int M, int HW, float alpha, float gamma,
+                        lsam_stream_t stream);
+int lsam_mask_loss_bwd(const float* logits, const float* targets, const float* coef, float* d_logits, int N, int M, int HW, float alpha,
+                       float gamma, lsam_stream_t stream);
+
 /* Shortcut of a q-pool block in one kernel: out = MaxPool2d(2, 2)(A . W^T + bias) over the token grid
  * (`shortcut = do_pool(self.proj(x_norm), self.pool)`, hieradet.py:139-140; do_pool: hieradet.py:27-41).
  * A bf16 [N_img*H*W][lda] (rows = NHWC tokens), W bf16 [N][ldw], bias fp32 [N]; out fp32 [N_img*(H/2)*(W/2)][ldo].
