@@ -7,3 +7,4 @@ from .lora_qkv import (LoRA_qkv, LoRABank, custom_load_lora_parameters, custom_s
                        wrap_image_encoder_lora)
 from .sam_heads import (Attention, Attention_LoRA, MaskDecoder, PromptEncoder, SAM2Base, TwoWayAttentionBlock,  # noqa: F401
                         TwoWayTransformer, wrap_decoder_lora)
+from .loss_fns import MultiStepMultiMasksAndIous, dice_loss, iou_loss, sigmoid_focal_loss  # noqa: F401
