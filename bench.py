@@ -198,6 +198,9 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plain-encoder", action="store_true", help="config 1: ImageEncoder.forward instead of forward_image")
+    ap.add_argument("--heads", action="store_true",
+                    help="config 1, informational (not BASELINE.json's metric): the whole prompted-frame step -- forward_image, SAM "
+                         "prompt encoder + mask decoder (fp32 operands), MultiStepMultiMasksAndIous, backward through all of it")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -238,10 +241,24 @@ def main():
         frames_per_step = B
         gf_per_frame = GF_BPLUS_FWD_BWD
 
+        if args.heads:
+            from image_segmentation_amd.loss_fns import CORE_LOSS_KEY, MultiStepMultiMasksAndIous
+            crit = MultiStepMultiMasksAndIous({"loss_mask": 20, "loss_dice": 1, "loss_iou": 1, "loss_class": 1}, supervise_all_iou=True,
+                                              iou_use_l1_loss=True, pred_obj_scores=True)       # config.yaml:26-37
+            yy, xx = torch.meshgrid(torch.arange(1024, device=device), torch.arange(1024, device=device), indexing="ij")
+            tgt = (((yy - 512) ** 2 + (xx - 512) ** 2) < 300 ** 2).float().expand(1, B, 1024, 1024).contiguous()
+            clicks = torch.full((B, 1, 2), 512.0, device=device)
+            clabels = torch.ones(B, 1, dtype=torch.int32, device=device)
+
         def step(i):
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 out = enc(img) if args.plain_encoder else sam.forward_image(img)
-            loss = fpn_loss(out)
+            if args.heads:
+                o = sam.forward_first_frame(out, clicks, clabels)
+                loss = crit([{"multistep_pred_multimasks_high_res": [o["high_res_multimasks"]], "multistep_pred_ious": [o["ious"]],
+                              "multistep_object_score_logits": [o["object_score_logits"]]}], tgt)[CORE_LOSS_KEY]
+            else:
+                loss = fpn_loss(out)
             loss.backward()
             reducer.reduce()
             opt.step()
@@ -326,7 +343,9 @@ def main():
     if rank == 0:
         model = "sam2.1_hiera_large + LoRA_qkv r=8" if config == 3 else "sam2.1_hiera_base_plus + LoRA_qkv r=4"
         what = {1: ("bf16 fwd+bwd of ImageEncoder.forward" if args.plain_encoder else
-                    "bf16 fwd+bwd of SAM2Base.forward_image (trunk + FPN neck + conv_s0/conv_s1)") + " (+LoRA-grad all-reduce, AdamW)",
+                    "bf16 fwd+bwd of SAM2Base.forward_image (trunk + FPN neck + conv_s0/conv_s1)")
+                   + (" + SAM heads (fp32) + MultiStepMultiMasksAndIous, fwd+bwd [informational: not BASELINE.json's metric]" if args.heads else "")
+                   + " (+LoRA-grad all-reduce, AdamW)",
                 3: "bf16 encoder-only inference (trunk + FPN neck, no grad)",
                 4: f"bf16 feature extraction (get_embedding + per-frame spatial mean), {steps * B * world} frames "
                    f"sharded by frame"}[config]

@@ -115,7 +115,12 @@ def lib() -> C.CDLL:
         L.lsam_upscale2x2_bwd.argtypes = [i, vp, vp, vp, vp, vp, C.c_float, vp, i, i, i, i, vp]
         L.lsam_mask_gate_bwd.argtypes = [vp, vp, vp, i, i, i, i, i, vp]
         L.lsam_bilinear_upsample_bwd.argtypes = [vp, vp, i, i, i, i, vp]
-        L.lsam_mask_loss_sums.argtypes = [vp, vp, vp, i, i, i, C.c_float, C.c_float, vp]
+        L.lsam_batched_outer_ws_floats.restype = C.c_size_t
+        L.lsam_batched_outer_ws_floats.argtypes = [i, i, i]
+        L.lsam_batched_outer.argtypes = [i, vp, vp, vp, vp, i, i, i, i, vp]
+        L.lsam_mask_loss_ws_floats.restype = C.c_size_t
+        L.lsam_mask_loss_ws_floats.argtypes = [i, i]
+        L.lsam_mask_loss_sums.argtypes = [vp, vp, vp, vp, i, i, i, C.c_float, C.c_float, vp]
         L.lsam_mask_loss_bwd.argtypes = [vp, vp, vp, vp, i, i, i, C.c_float, C.c_float, vp]
         L.lsam_kv_window_attention_image_bytes.restype = C.c_size_t
         L.lsam_kv_window_attention_image_bytes.argtypes = [i, i, i]
@@ -178,7 +183,7 @@ EXPORTED = [
     "lsam_add_rows", "lsam_mha_fwd", "lsam_pe_encode", "lsam_upscale2x2_fwd", "lsam_mask_gate", "lsam_bilinear_upsample",
     "lsam_attention_bwd_qpool", "lsam_neck_conv_image_bytes", "lsam_neck_conv_pack", "lsam_neck_level_fwd",
     "lsam_neck_topdown_bwd", "lsam_act_bwd", "lsam_mha_bwd", "lsam_upscale2x2_bwd", "lsam_mask_gate_bwd", "lsam_bilinear_upsample_bwd",
-    "lsam_mask_loss_sums", "lsam_mask_loss_bwd", "lsam_kv_window_attention_image_bytes", "lsam_kv_window_attention_pack", "lsam_kv_window_attention_fwd",
+    "lsam_batched_outer_ws_floats", "lsam_batched_outer", "lsam_mask_loss_ws_floats", "lsam_mask_loss_sums", "lsam_mask_loss_bwd", "lsam_kv_window_attention_image_bytes", "lsam_kv_window_attention_pack", "lsam_kv_window_attention_fwd",
     "lsam_neck_conv_split_image_bytes", "lsam_neck_conv_pack_split", "lsam_neck_level_fwd_split",
     "lsam_outer_reduce_static_max_ws", "lsam_outer_reduce_static_init", "lsam_outer_reduce_static",
 ]

@@ -427,6 +427,66 @@ int launch_bilinear_up_bwd(const float* dout, float* din, int BC, int H, int W, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// out[b][l][c] = sum_m G[b][m][l] U[b][m][c]: the hyper-network side of the mask product's backward (d hyper_in =
+// d_masks . upscaled^T, mask_decoder.py:238-239): G fp32 [B][M][L] (L <= 16 mask tokens), U T [B][M][C] (C <= 64), a
+// reduction over the M = 65536 pixels of every frame.  BO_SPLIT workgroups per frame sum row slices (tiles of 128 rows
+// staged in LDS, one (l, c) pair per thread), a second kernel adds the slices in a fixed order.
+// ---------------------------------------------------------------------------------------------
+constexpr int BO_SPLIT = 32, BO_ROWS = 128;
+template <typename T>
+__global__ __launch_bounds__(256) void batched_outer_kernel(const float* __restrict__ G, const T* __restrict__ U, float* __restrict__ part,
+                                                            int M, int L, int C) {
+    __shared__ float Gs[BO_ROWS][16], Us[BO_ROWS][64];
+    const int b = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
+    const int per = (M + BO_SPLIT - 1) / BO_SPLIT, m0 = sl * per, m1 = min(M, m0 + per);
+    const float* Gb = G + (size_t)b * M * L;
+    const T* Ub = U + (size_t)b * M * C;
+    const int np = L * C;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r0 = m0; r0 < m1; r0 += BO_ROWS) {
+        const int rows = min(BO_ROWS, m1 - r0);
+        for (int i = tid; i < BO_ROWS * L; i += 256) Gs[i / L][i % L] = (i / L) < rows ? Gb[(size_t)(r0 + i / L) * L + i % L] : 0.f;
+        for (int i = tid; i < BO_ROWS * C; i += 256) Us[i / C][i % C] = (i / C) < rows ? to_f(Ub[(size_t)(r0 + i / C) * C + i % C]) : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pr = tid + 256 * k;
+            if (pr < np) {
+                const int l = pr / C, c = pr % C;
+                float a = 0.f;
+                for (int r = 0; r < BO_ROWS; ++r) a += Gs[r][l] * Us[r][c];
+                acc[k] += a;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int pr = tid + 256 * k;
+        if (pr < np) part[((size_t)b * BO_SPLIT + sl) * np + pr] = acc[k];
+    }
+}
+__global__ void batched_outer_final_kernel(const float* __restrict__ part, float* __restrict__ out, int B, int np) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * np) return;
+    const int b = i / np, pr = i % np;
+    float s = 0.f;
+    for (int sl = 0; sl < BO_SPLIT; ++sl) s += part[((size_t)b * BO_SPLIT + sl) * np + pr];
+    out[i] = s;
+}
+size_t batched_outer_ws_floats(int B, int L, int C) { return (size_t)B * BO_SPLIT * L * C; }
+template <typename T>
+int launch_batched_outer(const float* G, const void* U, float* out, float* ws, int B, int M, int L, int C, hipStream_t s) {
+    LSAM_REQUIRE(G && U && out && ws && B > 0 && M > 0, LSAM_ERR_BAD_ARG, "batched_outer: null/empty");
+    LSAM_REQUIRE(L >= 1 && L <= 16 && C >= 1 && C <= 64 && L * C <= 1024, LSAM_ERR_UNSUPPORTED, "batched_outer: L <= 16, C <= 64 (L=%d C=%d)", L, C);
+    hipLaunchKernelGGL(batched_outer_kernel<T>, dim3(B, BO_SPLIT), dim3(256), 0, s, G, static_cast<const T*>(U), ws, M, L, C);
+    LSAM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(batched_outer_final_kernel, dim3((B * L * C + 255) / 256), dim3(256), 0, s, ws, out, B, L * C);
+    LSAM_LAUNCH_CHECK();
+    return LSAM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Mask losses (training/loss_fns.py): the per-mask sums every term is built from, in one pass over the logits:
 //   sums[n][m] = { sum focal(x, t),  sum sigmoid(x) t,  sum sigmoid(x),  sum t,  |x > 0 and t > 0|,  |x > 0 or t > 0| }
 // with focal = alpha_t * bce(x, t) * (1 - p_t)^gamma (sigmoid_focal_loss :58-98; alpha < 0: no alpha weighting), the dice
@@ -447,14 +507,16 @@ __device__ __forceinline__ void focal_terms(float x, float t, float alpha, float
     const float dmod = gamma == 2.0f ? -2.0f * om * dpt : (gamma == 0.0f ? 0.f : -gamma * __powf(fmaxf(om, 1e-30f), gamma - 1.0f) * dpt);
     dldx = at * ((p - t) * mod + ce * dmod);
 }
-__global__ __launch_bounds__(256) void mask_loss_sums_kernel(const float* __restrict__ x, const float* __restrict__ t, float* __restrict__ sums,
+constexpr int ML_SPLIT = 64;   // workgroups per candidate mask (a 1024^2 mask is 1 M pixels: one workgroup per mask took 3 ms)
+__global__ __launch_bounds__(256) void mask_loss_sums_kernel(const float* __restrict__ x, const float* __restrict__ t, float* __restrict__ part,
                                                              int M, int HW, float alpha, float gamma) {
     __shared__ float red[6][256];
-    const int n = blockIdx.x / M;
-    const float* xp = x + (size_t)blockIdx.x * HW;
+    const int nm = blockIdx.x, n = nm / M, sl = blockIdx.y;
+    const float* xp = x + (size_t)nm * HW;
     const float* tp = t + (size_t)n * HW;
+    const int per = (HW + ML_SPLIT - 1) / ML_SPLIT, i0 = sl * per, i1 = min(HW, i0 + per);
     float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int i = threadIdx.x; i < HW; i += 256) {
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
         const float xv = xp[i], tv = tp[i];
         float l, d, p;
         focal_terms(xv, tv, alpha, gamma, l, d, p);
@@ -475,7 +537,15 @@ __global__ __launch_bounds__(256) void mask_loss_sums_kernel(const float* __rest
         }
         __syncthreads();
     }
-    if (threadIdx.x < 6) sums[(size_t)blockIdx.x * 6 + threadIdx.x] = red[threadIdx.x][0];
+    if (threadIdx.x < 6) part[((size_t)nm * ML_SPLIT + sl) * 6 + threadIdx.x] = red[threadIdx.x][0];
+}
+__global__ void mask_loss_sums_final_kernel(const float* __restrict__ part, float* __restrict__ sums, int total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (mask, quantity)
+    if (i >= total) return;
+    const int nm = i / 6, j = i % 6;
+    float s = 0.f;
+    for (int sl = 0; sl < ML_SPLIT; ++sl) s += part[((size_t)nm * ML_SPLIT + sl) * 6 + j];   // fixed order
+    sums[i] = s;
 }
 __global__ void mask_loss_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t, const float* __restrict__ coef,
                                      float* __restrict__ dx, int M, int HW, float alpha, float gamma) {
@@ -495,9 +565,13 @@ __global__ void mask_loss_bwd_kernel(const float* __restrict__ x, const float* _
         dp[i] = v;
     }
 }
-int launch_mask_loss_sums(const float* x, const float* t, float* sums, int N, int M, int HW, float alpha, float gamma, hipStream_t s) {
-    LSAM_REQUIRE(x && t && sums && N > 0 && M > 0 && HW > 0, LSAM_ERR_BAD_ARG, "mask_loss_sums: null/empty");
-    hipLaunchKernelGGL(mask_loss_sums_kernel, dim3(N * M), dim3(256), 0, s, x, t, sums, M, HW, alpha, gamma);
+size_t mask_loss_ws_floats(int N, int M) { return (size_t)N * M * ML_SPLIT * 6; }
+int launch_mask_loss_sums(const float* x, const float* t, float* sums, float* ws, int N, int M, int HW, float alpha, float gamma,
+                          hipStream_t s) {
+    LSAM_REQUIRE(x && t && sums && ws && N > 0 && M > 0 && HW > 0, LSAM_ERR_BAD_ARG, "mask_loss_sums: null/empty");
+    hipLaunchKernelGGL(mask_loss_sums_kernel, dim3(N * M, ML_SPLIT), dim3(256), 0, s, x, t, ws, M, HW, alpha, gamma);
+    LSAM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mask_loss_sums_final_kernel, dim3((N * M * 6 + 255) / 256), dim3(256), 0, s, ws, sums, N * M * 6);
     LSAM_LAUNCH_CHECK();
     return LSAM_OK;
 }
@@ -547,9 +621,19 @@ int lsam_mask_gate_bwd(const float* d_masks, const float* obj_score, float* d_lo
 int lsam_bilinear_upsample_bwd(const float* dout, float* din, int BC, int H, int W, int scale, lsam_stream_t stream) {
     return launch_bilinear_up_bwd(dout, din, BC, H, W, scale, static_cast<hipStream_t>(stream));
 }
-int lsam_mask_loss_sums(const float* logits, const float* targets, float* sums, int N, int M, int HW, float alpha, float gamma,
-                        lsam_stream_t stream) {
-    return launch_mask_loss_sums(logits, targets, sums, N, M, HW, alpha, gamma, static_cast<hipStream_t>(stream));
+size_t lsam_batched_outer_ws_floats(int B, int L, int C) { return batched_outer_ws_floats(B, L, C); }
+int lsam_batched_outer(int u_dtype, const float* G, const void* U, float* out, float* workspace, int B, int M, int L, int C,
+                       lsam_stream_t stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (u_dtype == LSAM_F32) return launch_batched_outer<float>(G, U, out, workspace, B, M, L, C, s);
+    if (u_dtype == LSAM_BF16) return launch_batched_outer<bf16>(G, U, out, workspace, B, M, L, C, s);
+    set_error("batched_outer: bad dtype %d", u_dtype);
+    return LSAM_ERR_BAD_ARG;
+}
+size_t lsam_mask_loss_ws_floats(int N, int M) { return mask_loss_ws_floats(N, M); }
+int lsam_mask_loss_sums(const float* logits, const float* targets, float* sums, float* workspace, int N, int M, int HW, float alpha,
+                        float gamma, lsam_stream_t stream) {
+    return launch_mask_loss_sums(logits, targets, sums, workspace, N, M, HW, alpha, gamma, static_cast<hipStream_t>(stream));
 }
 int lsam_mask_loss_bwd(const float* logits, const float* targets, const float* coef, float* d_logits, int N, int M, int HW, float alpha,
                        float gamma, lsam_stream_t stream) {

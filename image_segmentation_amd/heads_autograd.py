@@ -179,10 +179,7 @@ class MaskProductFn(torch.autograd.Function):
             for b in range(B):
                 ops.linear(gT[b], hT[b], out=d_up[b])
         if ctx.needs_input_grad[1]:
-            g16 = torch.zeros(B, HW, 16, dtype=up.dtype, device=up.device)
-            g16[:, :, :L] = gT
-            d_hy = torch.stack([ops.outer_reduce(up[b], g16[b], L, transpose_out=True) for b in range(B)], 0)   # fp32 [B, L, C]
-            d_hy = _as(d_hy.view(B * L, C), hyper.dtype).view(B, L, C)
+            d_hy = _as(ops.batched_outer(g32, up).view(B * L, C), hyper.dtype).view(B, L, C)      # fp32 [B, L, C] reduction over HW
         return d_up, d_hy
 
 

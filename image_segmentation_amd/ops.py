@@ -624,7 +624,8 @@ def mask_loss_sums(logits: torch.Tensor, targets: torch.Tensor, alpha: float, ga
     HW = x[0, 0].numel()
     assert t.numel() == N * HW
     sums = torch.empty(N, M, 6, dtype=torch.float32, device=x.device)
-    check(lib().lsam_mask_loss_sums(ptr(x), ptr(t), ptr(sums), N, M, HW, alpha, gamma, stream()))
+    ws = torch.empty(lib().lsam_mask_loss_ws_floats(N, M), dtype=torch.float32, device=x.device)
+    check(lib().lsam_mask_loss_sums(ptr(x), ptr(t), ptr(sums), ptr(ws), N, M, HW, alpha, gamma, stream()))
     return sums
 
 
@@ -636,3 +637,16 @@ def mask_loss_bwd(logits: torch.Tensor, targets: torch.Tensor, coef: torch.Tenso
     dx = torch.empty_like(x)
     check(lib().lsam_mask_loss_bwd(ptr(x), ptr(t), ptr(c), ptr(dx), N, M, HW, alpha, gamma, stream()))
     return dx
+
+
+def batched_outer(G: torch.Tensor, U: torch.Tensor) -> torch.Tensor:
+    """fp32 [B, L, C] = sum_m G[b, m, l] U[b, m, c] for G fp32 [B, M, L] (L <= 16), U T [B, M, C] (C <= 64)."""
+    _need_gpu(G, U)
+    G = _f32c(G)
+    U = U.detach().contiguous()
+    B, M, L = G.shape
+    Cc = U.shape[2]
+    out = torch.empty(B, L, Cc, dtype=torch.float32, device=G.device)
+    ws = torch.empty(lib().lsam_batched_outer_ws_floats(B, L, Cc), dtype=torch.float32, device=G.device)
+    check(lib().lsam_batched_outer(dtype_code(U.dtype), ptr(G), ptr(U), ptr(out), ptr(ws), B, M, L, Cc, stream()))
+    return out

@@ -248,8 +248,14 @@ int lsam_bilinear_upsample_bwd(const float* dout, float* din, int BC, int H, int
  * weighting), sum p t, sum p, sum t, |x > 0 and t > 0|, |x > 0 or t > 0| }, from which the focal mean, the dice ratio and the
  * actual IoU of every candidate follow.  lsam_mask_loss_bwd takes coef fp32 [N][M][3] = d loss / d sums[., 0..2] and writes
  * d_logits = coef0 focal'(x) + (coef1 t + coef2) p (1 - p)  (zeros for candidates whose coefficients are all zero). */
-int lsam_mask_loss_sums(const float* logits, const float* targets, float* sums, int N, int M, int HW, float alpha, float gamma,
-                        lsam_stream_t stream);
+/* out[b][l][c] = sum_m G[b][m][l] U[b][m][c] (d hyper_in = d_masks . upscaled^T, the weight-like side of mask_decoder.py:238-239's
+ * product): G fp32 [B][M][L], U T [B][M][C], out fp32 [B][L][C]; L <= 16, C <= 64; workspace of lsam_batched_outer_ws_floats floats. */
+size_t lsam_batched_outer_ws_floats(int B, int L, int C);
+int lsam_batched_outer(int u_dtype, const float* G, const void* U, float* out, float* workspace, int B, int M, int L, int C,
+                       lsam_stream_t stream);
+size_t lsam_mask_loss_ws_floats(int N, int M);   /* floats of `workspace` (per-slice partial sums, summed in a fixed order) */
+int lsam_mask_loss_sums(const float* logits, const float* targets, float* sums, float* workspace, int N, int M, int HW, float alpha,
+                        float gamma, lsam_stream_t stream);
 int lsam_mask_loss_bwd(const float* logits, const float* targets, const float* coef, float* d_logits, int N, int M, int HW, float alpha,
                        float gamma, lsam_stream_t stream);
 

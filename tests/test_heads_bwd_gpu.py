@@ -174,3 +174,13 @@ def test_heads_backward_vs_restatement(dtype, tol):
         cos = F.cosine_similarity(f2.grad.float().flatten().cpu(), ref_df2.flatten(), dim=0).item()
         assert cos > 0.97 and all(torch.isfinite(w.grad).all() for w in lora), (cos, errs)
     assert float(ref_df2.norm()) > 0 and all(float(r.norm()) > 0 for r in ref_dl)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-5)])
+def test_batched_outer(dtype, tol):
+    from image_segmentation_amd import ops
+    B, M, L, C = 3, 5000, 8, 32
+    G, U = _rand(B, M, L, seed=1), _rand(B, M, C, seed=2).to(dtype)
+    got = ops.batched_outer(G.cuda(), U.cuda())
+    ref = torch.einsum("bml,bmc->blc", G.double(), U.double())
+    assert rel_err(got, ref) < tol
