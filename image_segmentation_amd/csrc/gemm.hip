@@ -1097,10 +1097,10 @@ __global__ __launch_bounds__(256) void skinny32_kernel(const GemmArgs p) {
     __shared__ __attribute__((aligned(16))) float part[3][2][64][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, lr = lane & 15;
-    const int m0 = blockIdx.x * 16;
+    const int m0 = blockIdx.x * 16, n0 = blockIdx.y * 32;
     const T* __restrict__ A = static_cast<const T*>(p.A) + (size_t)min(m0 + lr, p.M - 1) * p.lda;   // clamped rows are never stored
-    const T* __restrict__ W0 = static_cast<const T*>(p.W) + (size_t)lr * p.ldw;
-    const T* __restrict__ W1 = W0 + (size_t)16 * p.ldw;
+    const T* __restrict__ W0 = static_cast<const T*>(p.W) + (size_t)min(n0 + lr, p.N - 1) * p.ldw;
+    const T* __restrict__ W1 = static_cast<const T*>(p.W) + (size_t)min(n0 + 16 + lr, p.N - 1) * p.ldw;
     const int nks = (p.K + 31) / 32, per = (nks + 3) / 4;
     const int ks0 = wave * per, ks1 = min(nks, ks0 + per);
     auto ldf = [&](const T* row, int ks) -> frag {
@@ -1140,22 +1140,31 @@ __global__ __launch_bounds__(256) void skinny32_kernel(const GemmArgs p) {
             acc0 += *reinterpret_cast<const f32x4*>(part[w][0][lane]);
             acc1 += *reinterpret_cast<const f32x4*>(part[w][1][lane]);
         }
-        // lane: row m0 + lr, columns 4 g .. 4 g + 3 (acc0) and 16 + 4 g .. (acc1)
-        if ((p.flags & LSAM_EPI_OUT_F32) || sizeof(T) == 4) {
-            float* o = static_cast<float*>(p.out) + (size_t)(m0 + lr) * p.ldo + 4 * g;
-            store4(o, acc0);
-            store4(o + 16, acc1);
-        } else {
-            T* o = static_cast<T*>(p.out) + (size_t)(m0 + lr) * p.ldo + 4 * g;
-            store4(o, acc0);
-            store4(o + 16, acc1);
-        }
+        // lane: row m0 + lr, columns n0 + 4 g .. + 3 (acc0) and n0 + 16 + 4 g .. (acc1); N % 4 == 0
+        const int m = m0 + lr;
+        auto finish = [&](f32x4 v, int n) {
+            if (n >= p.N) return;
+            if (p.bias) v += load4(p.bias + n);
+            if (p.flags & LSAM_EPI_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (p.flags & LSAM_EPI_SIGMOID) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = 1.0f / (1.0f + __expf(-v[r]));
+            }
+            if (p.res) v += load4(p.res + (size_t)(p.res_row_mod > 0 ? m % p.res_row_mod : m) * p.ldres + n);
+            if ((p.flags & LSAM_EPI_OUT_F32) || sizeof(T) == 4) store4(static_cast<float*>(p.out) + (size_t)m * p.ldo + n, v);
+            else store4(static_cast<T*>(p.out) + (size_t)m * p.ldo + n, v);
+        };
+        finish(acc0, n0 + 4 * g);
+        finish(acc1, n0 + 16 + 4 * g);
     }
 }
 
 template <typename T> static int launch_skinny32(const GemmArgs& a, hipStream_t s) {
     const int rec = prof_begin(s);
-    hipLaunchKernelGGL(skinny32_kernel<T>, dim3(cdiv(a.M, 16)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(skinny32_kernel<T>, dim3(cdiv(a.M, 16), cdiv(a.N, 32)), dim3(256), 0, s, a);
     LSAM_LAUNCH_CHECK();
     prof_end(rec, s, 2.0 * a.M * a.N * a.K, (int)sizeof(T) * 1000 + 32, a.M, a.N, a.K);
     return LSAM_OK;
@@ -1207,6 +1216,12 @@ template <typename T> int launch_gemm(const GemmArgs& a, hipStream_t s) {
             return LSAM_OK;
         }
     }
+    // few rows (the SAM heads' token stream: 8 tokens per frame) or N = 32 (the LoRA u / t columns): the streaming kernel --
+    // 16 x 32 outputs per workgroup, K split over its waves, no LDS staging -- instead of a tile kernel's serial k-loop on
+    // one or two workgroups
+    if (a.pool_w == 0 && !a.aux && !a.out2 && (a.flags & ~(LSAM_EPI_OUT_F32 | LSAM_EPI_RELU | LSAM_EPI_SIGMOID)) == 0 &&
+        (a.M <= 512 || (a.N == 32 && a.M >= 1024 && !a.bias && !a.res)))
+        return launch_skinny32<T>(a, s);
     // ReLU / sigmoid epilogues (the SAM heads' small MLPs) exist in the generic kernel only
     if (a.flags & (LSAM_EPI_RELU | LSAM_EPI_SIGMOID)) {
         LSAM_REQUIRE(a.pool_w == 0, LSAM_ERR_UNSUPPORTED, "linear: ReLU / sigmoid with the pooled epilogue");
@@ -1250,9 +1265,6 @@ template <typename T> int launch_gemm(const GemmArgs& a, hipStream_t s) {
         return of32 ? launch_v2<T, 1, true>(a, s) : launch_v2<T, 1, sizeof(T) == 4>(a, s);
     }
     if (a.N % 112 == 0) return launch_cfg<T, 2, 7, 4, 1>(a, s);
-    // skinny outputs (the LoRA u = xn . A^T and t = dqkv . B products): a streaming kernel without LDS staging
-    if (a.N == 32 && a.M >= 1024 && !a.bias && !a.res && !a.aux && !a.out2 && (a.flags & ~LSAM_EPI_OUT_F32) == 0)
-        return launch_skinny32<T>(a, s);
     return launch_cfg<T, 4, 4, 2, 2>(a, s);
 }
 template int launch_gemm<float>(const GemmArgs&, hipStream_t);
