@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblsam.so")
 
 F32, BF16 = 0, 1
-EPI_GELU, EPI_GELU_BWD, EPI_OUT_F32, EPI_SAVE_PRE, EPI_RELU, EPI_SIGMOID = 1, 2, 4, 8, 16, 32
+EPI_GELU, EPI_GELU_BWD, EPI_OUT_F32, EPI_SAVE_PRE, EPI_RELU, EPI_SIGMOID, EPI_FEW_ROWS = 1, 2, 4, 8, 16, 32, 64
 
 
 class LsamError(RuntimeError):

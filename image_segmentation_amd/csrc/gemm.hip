@@ -1178,8 +1178,11 @@ bool gemm_pool_supported(int H, int W, int N) {
     return W % tw == 0 && H % (256 / tw) == 0;
 }
 
-template <typename T> int launch_gemm(const GemmArgs& a, hipStream_t s) {
+template <typename T> int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     constexpr int EPC = Tr<T>::EPC;
+    const bool few_rows = (a_in.flags & LSAM_EPI_FEW_ROWS) != 0;
+    GemmArgs a = a_in;
+    a.flags &= ~LSAM_EPI_FEW_ROWS;
     LSAM_REQUIRE(a.A && a.W && a.out, LSAM_ERR_BAD_ARG, "linear: null operand");
     LSAM_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, LSAM_ERR_BAD_ARG, "linear: empty shape %dx%dx%d", a.M, a.N, a.K);
     LSAM_REQUIRE(a.N % 8 == 0 && a.K % EPC == 0, LSAM_ERR_UNSUPPORTED,
@@ -1216,11 +1219,12 @@ template <typename T> int launch_gemm(const GemmArgs& a, hipStream_t s) {
             return LSAM_OK;
         }
     }
-    // few rows (the SAM heads' token stream: 8 tokens per frame) or N = 32 (the LoRA u / t columns): the streaming kernel --
-    // 16 x 32 outputs per workgroup, K split over its waves, no LDS staging -- instead of a tile kernel's serial k-loop on
-    // one or two workgroups
-    if (a.pool_w == 0 && !a.aux && !a.out2 && (a.flags & ~(LSAM_EPI_OUT_F32 | LSAM_EPI_RELU | LSAM_EPI_SIGMOID)) == 0 &&
-        (a.M <= 512 || (a.N == 32 && a.M >= 1024 && !a.bias && !a.res)))
+    // LSAM_EPI_FEW_ROWS (the SAM heads' token stream: 8 tokens per frame; the caller says so, the choice never depends on M, so
+    // results do not depend on the batch size) or N = 32 (the LoRA u / t columns): the streaming kernel -- 16 x 32 outputs per
+    // workgroup, K split over its waves, no LDS staging -- instead of a tile kernel's serial k-loop on one or two workgroups
+    const bool stream_ok = a.pool_w == 0 && !a.aux && !a.out2 && (a.flags & ~(LSAM_EPI_OUT_F32 | LSAM_EPI_RELU | LSAM_EPI_SIGMOID)) == 0;
+    LSAM_REQUIRE(!few_rows || stream_ok, LSAM_ERR_UNSUPPORTED, "linear: FEW_ROWS goes with bias / ReLU / sigmoid / OUT_F32 / res only");
+    if (few_rows || (stream_ok && a.N == 32 && a.M >= 1024 && !a.bias && !a.res && (a.flags & ~LSAM_EPI_OUT_F32) == 0))
         return launch_skinny32<T>(a, s);
     // ReLU / sigmoid epilogues (the SAM heads' small MLPs) exist in the generic kernel only
     if (a.flags & (LSAM_EPI_RELU | LSAM_EPI_SIGMOID)) {

@@ -31,12 +31,13 @@ def _as(g32: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 
 class LinearFn(torch.autograd.Function):
     """y = act(x @ W^T + b) (+ res): x T [M, K], packed W T [Npad, Kpad], fp32 bias, fp32 res [M, Npad]; returns [M, Npad]
-    (fp32 with out_f32, else T).  `w_param` is the module's weight when it is trainable (a LoRA factor), else None."""
+    (fp32 with out_f32, else T); `few_rows` = LSAM_EPI_FEW_ROWS (the token stream).  `w_param` is the module's weight when it is trainable (a LoRA factor), else None."""
 
     @staticmethod
-    def forward(ctx, x, res, w_param, pack, relu, sigmoid, out_f32):
+    def forward(ctx, x, res, w_param, pack, relu, sigmoid, out_f32, few_rows=False):
         w, b, wT, n = pack
-        y = ops.linear(x, w, b, res=res, K=x.shape[1], relu=relu, sigmoid=sigmoid, out_f32=out_f32)
+        y = ops.linear(x, w, b, res=res, K=x.shape[1], relu=relu, sigmoid=sigmoid, out_f32=out_f32, few_rows=few_rows)
+        ctx.few_rows = few_rows
         ctx.pack, ctx.relu, ctx.sigmoid, ctx.has_res = pack, relu, sigmoid, res is not None
         ctx.x_dtype, ctx.k = x.dtype, x.shape[1]
         need_w = w_param is not None and w_param.requires_grad
@@ -57,7 +58,7 @@ class LinearFn(torch.autograd.Function):
         gT = _as(g32, w.dtype)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.linear(gT, wT, K=gT.shape[1], out_f32=ctx.x_dtype == torch.float32)      # dY . W, [M, Kpad]
+            dx = ops.linear(gT, wT, K=gT.shape[1], out_f32=ctx.x_dtype == torch.float32, few_rows=ctx.few_rows)      # dY . W, [M, Kpad]
             if dx.shape[1] != ctx.k:
                 dx = dx[:, :ctx.k].contiguous()
         dw = None
@@ -74,7 +75,7 @@ class LinearFn(torch.autograd.Function):
                 dw = ops.outer_reduce(gT[:, :nw].contiguous(), x16, kw, transpose_out=False)     # [nw, kw]
             else:
                 raise RuntimeError("LinearFn: weight gradients exist for rank <= 16 LoRA factors only")
-        return dx, d_res, dw, None, None, None, None
+        return dx, d_res, dw, None, None, None, None, None
 
 
 class LayerNormFn(torch.autograd.Function):

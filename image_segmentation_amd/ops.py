@@ -65,7 +65,7 @@ def linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None
            res: Optional[torch.Tensor] = None, res_row_mod: int = 0, gelu: bool = False,
            gelu_bwd_aux: Optional[torch.Tensor] = None, out_f32: bool = False, save_pre: bool = False,
            out: Optional[torch.Tensor] = None, K: Optional[int] = None, N: Optional[int] = None, relu: bool = False,
-           sigmoid: bool = False):
+           sigmoid: bool = False, few_rows: bool = False):
     """out = epilogue(A[:, :K] @ W[:N, :K].T + bias) + res   (see lsam_linear)."""
     _need_gpu(A, W, bias, res)
     assert A.dtype == W.dtype
@@ -82,7 +82,7 @@ def linear(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None
     out2 = torch.empty(M, N, dtype=A.dtype, device=A.device) if save_pre else None
     flags = (_C.EPI_GELU if gelu else 0) | (_C.EPI_GELU_BWD if gelu_bwd_aux is not None else 0) | \
         (_C.EPI_OUT_F32 if out_f32 else 0) | (_C.EPI_SAVE_PRE if save_pre else 0) | (_C.EPI_RELU if relu else 0) | \
-        (_C.EPI_SIGMOID if sigmoid else 0)
+        (_C.EPI_SIGMOID if sigmoid else 0) | (_C.EPI_FEW_ROWS if few_rows else 0)
     ldres = res.stride(0) if res is not None else 0
     ldaux = gelu_bwd_aux.stride(0) if gelu_bwd_aux is not None else 0
     check(lib().lsam_linear(dtype_code(A.dtype), ptr(A), lda, ptr(W), ldw, ptr(bias), ptr(res), ldres,

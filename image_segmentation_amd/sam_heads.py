@@ -292,10 +292,12 @@ class SAM2Base(nn.Module):
 
     def _lin(self, x, mod, dt, weight2d=None, bias=None, name=None, keep_pad=False, **kw):
         """x T [M, K] -> [M, N] through mod's packed weight (N, K zero-padded to multiples of 8; `keep_pad` returns the
-        padded columns, all zero, for a following product over them)."""
+        padded columns, all zero, for a following product over them).  `few_rows`: x is the token stream (a handful of rows
+        per frame), see LSAM_EPI_FEW_ROWS; a property of the call site, never of the batch size."""
         pack = self._packs.linear(mod, dt, weight2d, bias, name)
         wp = mod.weight if (weight2d is None and mod.weight.requires_grad) else None      # a trainable LoRA factor
-        out = HA.LinearFn.apply(x, kw.get("res"), wp, pack, kw.get("relu", False), kw.get("sigmoid", False), kw.get("out_f32", False))
+        out = HA.LinearFn.apply(x, kw.get("res"), wp, pack, kw.get("relu", False), kw.get("sigmoid", False), kw.get("out_f32", False),
+                                kw.get("few_rows", False))
         n = pack[3]
         return out if keep_pad or out.shape[1] == n else out[:, :n]
 
@@ -310,7 +312,7 @@ class SAM2Base(nn.Module):
         n = len(mlp.layers)
         for i, layer in enumerate(mlp.layers):
             last = i == n - 1
-            x = self._lin(x, layer, dt, relu=not last, sigmoid=last and mlp.sigmoid_output, out_f32=last)
+            x = self._lin(x, layer, dt, relu=not last, sigmoid=last and mlp.sigmoid_output, out_f32=last, few_rows=True)
             if not last and x.stride(0) != x.shape[1]:
                 x = x.contiguous()
         return x
@@ -320,15 +322,16 @@ class SAM2Base(nn.Module):
         fp32 [B*nq, D] = (residual +) out_proj(softmax(q k^T / sqrt(hd)) v)."""
         lora = isinstance(att, Attention_LoRA)
         tq = tv = None
+        fq, fk = q.shape[0] <= 16 * B, k.shape[0] <= 16 * B     # which side is the token stream
         if lora:   # the rank-r updates as fp32 residuals of the projections
-            tq = self._lin(self._lin(q, att.A_q, dt, keep_pad=True), att.B_q, dt, out_f32=True)
-            tv = self._lin(self._lin(v, att.A_v, dt, keep_pad=True), att.B_v, dt, out_f32=True)
-        qh = self._lin(q, att.q_proj, dt, res=tq)
-        kh = self._lin(k, att.k_proj, dt)
-        vh = self._lin(v, att.v_proj, dt, res=tv)
+            tq = self._lin(self._lin(q, att.A_q, dt, keep_pad=True, few_rows=fq), att.B_q, dt, out_f32=True, few_rows=fq)
+            tv = self._lin(self._lin(v, att.A_v, dt, keep_pad=True, few_rows=fk), att.B_v, dt, out_f32=True, few_rows=fk)
+        qh = self._lin(q, att.q_proj, dt, res=tq, few_rows=fq)
+        kh = self._lin(k, att.k_proj, dt, few_rows=fk)
+        vh = self._lin(v, att.v_proj, dt, res=tv, few_rows=fk)
         c = att.internal_dim
         o = HA.MhaFn.apply(qh.reshape(B, -1, c), kh.reshape(B, -1, c), vh.reshape(B, -1, c), att.num_heads)
-        return self._lin(o.view(-1, c), att.out_proj, dt, res=residual, out_f32=True)
+        return self._lin(o.view(-1, c), att.out_proj, dt, res=residual, out_f32=True, few_rows=fq)
 
     def _ln(self, norm: nn.LayerNorm, x):
         return HA.LayerNormFn.apply(x, norm.weight.detach(), norm.bias.detach(), norm.eps)
@@ -389,8 +392,8 @@ class SAM2Base(nn.Module):
             k = self._add(keys, key_pe, dt)
             queries = self._attention(blk.cross_attn_token_to_image, q, k, self._T(keys, dt), B, dt, residual=queries)
             queries = self._ln(blk.norm2, queries)
-            h = self._lin(self._T(queries, dt), blk.mlp.layers[0], dt, relu=True)
-            queries = self._lin(h, blk.mlp.layers[1], dt, res=queries, out_f32=True)
+            h = self._lin(self._T(queries, dt), blk.mlp.layers[0], dt, relu=True, few_rows=True)
+            queries = self._lin(h, blk.mlp.layers[1], dt, res=queries, out_f32=True, few_rows=True)
             queries = self._ln(blk.norm3, queries)
             q = self._add(queries, point_embedding, dt)
             keys = self._attention(blk.cross_attn_image_to_token, k, q, self._T(queries, dt), B, dt, residual=keys)
@@ -423,7 +426,7 @@ class SAM2Base(nn.Module):
         if self.pred_obj_scores:
             head = dec.pred_obj_score_head
             obj = self._mlp(head, hsT[:, 0].contiguous(), dt) if isinstance(head, MLP) else \
-                self._lin(hsT[:, 0].contiguous(), head, dt, out_f32=True)
+                self._lin(hsT[:, 0].contiguous(), head, dt, out_f32=True, few_rows=True)
         else:
             obj = torch.full((B, 1), 10.0, dtype=torch.float32, device=dev)
         return logits, iou.contiguous(), obj.contiguous()

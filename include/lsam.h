@@ -58,7 +58,10 @@ enum {
     LSAM_EPI_OUT_F32 = 4,   /* out is float* even in bf16 mode                                         */
     LSAM_EPI_SAVE_PRE = 8,  /* also write (acc + bias) before the activation to out2 (T)                */
     LSAM_EPI_RELU = 16,     /* out = max(acc + bias, 0)         (sam/transformer.py MLPBlock, sam2_utils.MLP of the SAM heads) */
-    LSAM_EPI_SIGMOID = 32   /* out = sigmoid(acc + bias)        (MLP(sigmoid_output=True): the IoU head, mask_decoder.py:96-102) */
+    LSAM_EPI_SIGMOID = 32,  /* out = sigmoid(acc + bias)        (MLP(sigmoid_output=True): the IoU head, mask_decoder.py:96-102) */
+    LSAM_EPI_FEW_ROWS = 64  /* caller hint: A is a short stream (the SAM heads' 8 tokens per frame): run the streaming kernel, K split
+                             * over a workgroup's waves.  Same result up to fp32 summation order; the order never depends on M, so
+                             * results stay independent of the batch size.  Only with bias / RELU / SIGMOID / OUT_F32 / res.       */
 };
 
 /* out[M,N] = epilogue( A[M,K] . W[N,K]^T + bias[N] ) + res

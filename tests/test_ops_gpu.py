@@ -549,3 +549,31 @@ def test_linear_skinny32(dt, M, K):
     assert torch.equal(buf[:, :K], a)                                   # the operand columns are untouched
     o32 = ops.linear(a, w, out_f32=True)
     assert o32.dtype == torch.float32 and rel_err(o32.double(), ref) < (1e-6 if dt == torch.float32 else 1e-5 + 0)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,epi", [(8, 256, 256, "relu"), (130, 2048, 256, "none"), (37, 8, 256, "sigmoid"), (128, 256, 2048, "res"),
+                                       (5, 40, 8, "none"), (4100, 128, 264, "res")])
+def test_linear_few_rows(dt, M, N, K, epi):
+    """LSAM_EPI_FEW_ROWS: the streaming kernel with the bias / activation / residual epilogue, ragged M and N, and the same
+    rows whatever the batch around them (the K split never depends on M)."""
+    from image_segmentation_amd import ops
+    g = torch.Generator().manual_seed(M * N + K)
+    a = torch.randn(M, K, generator=g).to(dt).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dt).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda() if epi == "res" else None
+    ref = a.double() @ w.double().t() + b.double()
+    ref = ref.relu() if epi == "relu" else ref.sigmoid() if epi == "sigmoid" else ref + res.double() if epi == "res" else ref
+    out = ops.linear(a, w, b, res=res, relu=epi == "relu", sigmoid=epi == "sigmoid", out_f32=True, few_rows=True)
+    assert rel_err(out.double(), ref) < (2e-6 if dt == torch.float32 else 1e-5)
+    tile = ops.linear(a, w, b, res=res, relu=epi == "relu", sigmoid=epi == "sigmoid", out_f32=True)
+    assert rel_err(out, tile) < 2e-6
+    k = min(M, 3)
+    part = ops.linear(a[:k], w, b, res=None if res is None else res[:k], relu=epi == "relu", sigmoid=epi == "sigmoid", out_f32=True, few_rows=True)
+    assert torch.equal(part, out[:k])
+    if dt == torch.bfloat16:
+        ot = ops.linear(a, w, b, res=res, relu=epi == "relu", sigmoid=epi == "sigmoid", few_rows=True)
+        assert ot.dtype == dt and rel_err(ot.double(), ref) < 5e-3
+    with pytest.raises(Exception):
+        ops.linear(a, w, b, gelu=True, few_rows=True)
