@@ -253,6 +253,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlpblock_kernel(cons
 #endif
                 __builtin_amdgcn_sched_barrier(0);
                 mlp_lds_wait();
+                __builtin_amdgcn_sched_barrier(0);   // without it the first fc2 MFMA is scheduled above the wait (tools/asm_lds_hazard.py)
 #pragma unroll
                 for (int i = 0; i < 2 * NTO; ++i)
 #pragma unroll

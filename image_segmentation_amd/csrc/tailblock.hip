@@ -452,21 +452,28 @@ constexpr int PDMAB(int nb) { return nb / PAIR_DMA_FRAC > 0 ? nb / PAIR_DMA_FRAC
 #ifndef PAIR_BSP
 #define PAIR_BSP 4
 #endif
+#ifndef PAIR_BSM_ODD
+#define PAIR_BSM_ODD 2
+#endif
 #ifndef PAIR_BSM
 #define PAIR_BSM 2   // whole step, A/B on one box (with PAIR_DMA_FRAC 2): 4 -> 870, 2 -> 876, 1 -> 872 frames/s
 #endif
 template <int KS, int NTO> struct PairImg {
-    static_assert(KS % 2 == 0 && NTO == 2 * KS, "pair split needs an even number of k-steps");
-    static constexpr int KSH = KS / 2, NTH = NTO / 2;
-    static constexpr int NPC = KS / 2;              // proj chunks: two k-steps of all row tiles
-    static constexpr int FR = 2 * NTO;              // fragments per chunk; wave half hh owns [hh FR/2, (hh+1) FR/2)
-    static constexpr int HF = FR / 2;               //   proj: [kl][ntl]; MLP: fc1 [ksl][t] (2 KSH), then fc2 [ntl] (NTH)
+    // Odd KS (d = 224: 7 k-steps, 7 column tiles per wave): a wave's 112 channels are 3 1/2 k-steps of fc1's K -- its last
+    // k-step has the upper 16 k-slots empty (zero operand slots, zero weights: 8 fc1 fragments where 7 would do), and the last
+    // proj chunk holds one k-step.
+    static_assert(NTO == 2 * KS, "d = 32 KS = 16 NTO");
+    static constexpr int KSH = (KS + 1) / 2, NTH = NTO / 2;
+    static constexpr int NPC = (KS + 1) / 2;        // proj chunks: two k-steps of all row tiles
+    static constexpr int HFP = 2 * NTH, HFM = 2 * KSH + NTH;   // fragments a wave uses of a proj / an MLP chunk
+    static constexpr int HF = HFP > HFM ? HFP : HFM;           //   proj: [kl][ntl]; MLP: fc1 [ksl][t] (2 KSH), then fc2 [ntl] (NTH)
+    static constexpr int FR = 2 * HF;               // fragments per chunk; wave half hh owns [hh HF, (hh+1) HF)
     static constexpr int B1_OFF = FR * 1024;        // fc1 biases of the chunk (they seed the fc1 accumulators)
     static constexpr int CHUNK_B = (FR + 1) * 1024;
     static constexpr int VEC = 16 * NTO;
-    static constexpr int XCH_OFF = 2 * CHUNK_B;     // exchange: [2 parities]{fc1 partials [8 waves][1 KiB], GELU halves [8 waves][1 KiB]}
-    static constexpr int STAT_OFF = XCH_OFF + 2 * 8 * 2048;   // LayerNorm statistics: [2][8 waves][32] floats
-    static constexpr int LDS_B = STAT_OFF + 2 * 8 * 32 * 4;
+    static constexpr int XCH_OFF = 2 * CHUNK_B;     // exchange: [2 parities]{fc1 partials [NW waves][1 KiB], GELU halves [NW waves][1 KiB]}
+    static constexpr int stat_off(int nw) { return XCH_OFF + 2 * nw * 2048; }   // LayerNorm statistics: [2][NW waves][32] floats
+    static constexpr int lds_bytes(int nw) { return stat_off(nw) + 2 * nw * 32 * 4; }
 };
 
 template <int KS, int NTO>
@@ -489,15 +496,15 @@ __global__ void pack_tailpair_kernel(const float* __restrict__ wproj, const floa
         if (ck < I::NPC) {
             const int kl = fl / I::NTH, ntl = fl % I::NTH, ks = 2 * ck + kl;
             const int row = 16 * (I::NTH * hh + ntl) + lr, k = 32 * ks + 8 * g + j;
-            v = wproj[(size_t)row * d + k];
+            if (fl < I::HFP && ks < KS) v = wproj[(size_t)row * d + k];
         } else {
             const int c = ck - I::NPC;
-            const int perm = 16 * (j >> 2) + 4 * g + (j & 3);
             if (fl < 2 * I::KSH) {   // fc1 of hidden chunk c, K half hh; row tile 0 of a half is the one it finalises
-                const int ksl = fl >> 1, t = (fl & 1) ^ hh, ks = I::KSH * hh + ksl;
-                const int hrow = 32 * c + 16 * t + lr, ch = 32 * ks + perm;
-                if (c < nch) v = w1[(size_t)hrow * d + ch];
-            } else {                 // fc2 of hidden chunk c - 2, output half hh; k-slots 0..3 = its own hidden tile
+                // k-slot j of the wave's k-step ksl = channel 4 g + (j & 3) of its column tile 2 ksl + (j >> 2)
+                const int ksl = fl >> 1, t = (fl & 1) ^ hh, ctile = 2 * ksl + (j >> 2);
+                const int hrow = 32 * c + 16 * t + lr, ch = 16 * (I::NTH * hh + ctile) + 4 * g + (j & 3);
+                if (c < nch && ctile < I::NTH) v = w1[(size_t)hrow * d + ch];
+            } else if (fl < I::HFM) {   // fc2 of hidden chunk c - 2, output half hh; k-slots 0..3 = its own hidden tile
                 const int ntl = fl - 2 * I::KSH, row = 16 * (I::NTH * hh + ntl) + lr;
                 const int hcol = 32 * (c - 2) + 16 * ((j >> 2) ^ hh) + 4 * g + (j & 3);
                 if (c >= 2 && c - 2 < nch) v = w2[(size_t)row * hid + hcol];
@@ -526,10 +533,13 @@ __device__ __forceinline__ bf16x8 lds_read_b128(unsigned addr) {
     return v;
 }
 
-template <int KS, int NTO>
-__global__ __launch_bounds__(512) void tailpair_kernel(const TailBlockArgs p) {
+// NW = 8: one workgroup per CU; NW = 4: two (they drift apart, so one's HBM phase -- residual and a loads, stores -- falls
+// under the other's MFMAs, at twice the weight traffic from L2)
+template <int KS, int NTO, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void tailpair_kernel(const TailBlockArgs p) {
     using I = PairImg<KS, NTO>;
-    constexpr int KSH = I::KSH, NTH = I::NTH, HF = I::HF, MT = 2, NW = 8, CB = I::CHUNK_B, NF = CB / 1024;
+    constexpr int KSH = I::KSH, NTH = I::NTH, HF = I::HF, MT = 2, CB = I::CHUNK_B, NF = CB / 1024;
+    constexpr int XPAR = NW * 2048, XGELU = NW * 1024;   // exchange area: bytes per parity, offset of the GELU halves
     constexpr int TPG = 16 * MT * (NW / 2), d = 16 * NTO;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
 
@@ -551,6 +561,9 @@ __global__ __launch_bounds__(512) void tailpair_kernel(const TailBlockArgs p) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(img), 0, nck * CB, 0x00020000);
     const unsigned dma_vo = (unsigned)(lane * 16 + wave * 1024);
     auto issue_piece = [&](int ck, int buf, int i) {
+#if TAIL_ABL & 32
+        ck &= 1;   // timing only: the stream stays on two L2-hot chunks
+#endif
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (tail_lds_p)(smem + buf * CB + (wave + NW * i) * 1024), 16, dma_vo,
                                                  ck * CB + NW * i * 1024, 0, 0);
     };
@@ -567,7 +580,7 @@ __global__ __launch_bounds__(512) void tailpair_kernel(const TailBlockArgs p) {
         for (int i = b * PPB; i < (b + 1) * PPB && i < NP; ++i) issue_piece(ck, buf, i);
     };
     const unsigned lds0 = (unsigned)(size_t)(tail_lds_cp)(smem);
-    float* stat = reinterpret_cast<float*>(smem + I::STAT_OFF);
+    float* stat = reinterpret_cast<float*>(smem + I::stat_off(NW));
     // LayerNorm statistics of the pair's 32 tokens: each wave reduces its 224 channels, the halves meet in LDS
     auto pair_stats = [&](const f32x4 (&acc)[MT][NTH], float (&mean)[MT], float (&rstd)[MT]) {
         float s[MT], q[MT];
@@ -605,7 +618,7 @@ __global__ __launch_bounds__(512) void tailpair_kernel(const TailBlockArgs p) {
     };
 
     // the exchange area is read one iteration before its first real contents exist: it must hold finite numbers
-    for (int i = tid; i < 2 * 16384 / 16; i += 64 * NW)
+    for (int i = tid; i < 2 * XPAR / 16; i += 64 * NW)
         *reinterpret_cast<f32x4*>(smem + I::XCH_OFF + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ngroups = (M + TPG - 1) / TPG;
     int buf = 0;
@@ -628,7 +641,7 @@ __global__ __launch_bounds__(512) void tailpair_kernel(const TailBlockArgs p) {
             for (int mt = 0; mt < MT; ++mt) {
                 arow[mt] = A + (size_t)mrow[mt] * p.lda + 8 * g;
 #pragma unroll
-                for (int kl = 0; kl < 2; ++kl) afn[mt][kl] = *reinterpret_cast<const bf16x8*>(arow[mt] + 32 * kl);
+                for (int kl = 0; kl < 2; ++kl) afn[mt][kl] = *reinterpret_cast<const bf16x8*>(arow[mt] + 32 * kl);   // KS >= 2
             }
 #pragma unroll
             for (int nt = 0; nt < NTH; ++nt) {
@@ -646,27 +659,34 @@ __global__ __launch_bounds__(512) void tailpair_kernel(const TailBlockArgs p) {
 #pragma unroll
                     for (int kl = 0; kl < 2; ++kl) {
                         af[mt][kl] = afn[mt][kl];
-                        if constexpr (pc + 1 < I::NPC)
-                            afn[mt][kl] = *reinterpret_cast<const bf16x8*>(arow[mt] + 32 * (2 * (pc + 1) + kl));
+                        if constexpr (pc + 1 < I::NPC) {
+                            if (2 * (pc + 1) + kl < KS)   // compile-time after unrolling; odd KS: the last chunk has one k-step
+                                afn[mt][kl] = *reinterpret_cast<const bf16x8*>(arow[mt] + 32 * (2 * (pc + 1) + kl));
+                        }
                     }
                 unsigned ln;
                 asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
                 const unsigned base = lds0 + buf * CB + hh * (HF * 1024) + ln * 16u;
-                constexpr int BS = PAIR_BSP, NBP = HF / BS;
-                static_assert(HF % BS == 0, "fragment batches");
+                constexpr int BS = PAIR_BSP, NBP = (HF + BS - 1) / BS;
+                constexpr int LIM = 2 * pc + 1 < KS ? I::HFP : NTH;   // fragments of this chunk that are used (odd KS: one k-step in the last)
                 bf16x8 w[2][BS];
                 lds_frags<0, BS>(base, w[0]);
                 static_for<0, NBP>([&](auto b_) {
                     constexpr int b = decltype(b_)::value;
                     lds_wait();
-                    if constexpr (b + 1 < NBP) lds_frags<(b + 1) * BS, BS>(base, w[(b + 1) & 1]);
+                    // only fragments that are used: a register an asm read targets and nothing consumes is reused at once by the
+                    // compiler, and the late LDS return would land on its new contents
+                    if constexpr (b + 1 < NBP && (b + 1) * BS < LIM)
+                        lds_frags<(b + 1) * BS, (LIM - (b + 1) * BS < BS ? LIM - (b + 1) * BS : BS)>(base, w[(b + 1) & 1]);
                     if constexpr (b < PDMAB(NBP)) issue_part(b_, std::integral_constant<int, PDMAB(NBP)>{}, pc + 1, buf ^ 1);   // pc + 1 <= NPC < nck
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < BS; ++i) {
                         const int fl = b * BS + i, kl = fl / NTH, ntl = fl % NTH;
+                        if (fl < LIM) {
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) mma16(w[b & 1][i], af[mt][kl], acc[mt][ntl]);
+                            for (int mt = 0; mt < MT; ++mt) mma16(w[b & 1][i], af[mt][kl & 1], acc[mt][ntl]);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
@@ -683,12 +703,19 @@ __global__ __launch_bounds__(512) void tailpair_kernel(const TailBlockArgs p) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int nt = 2 * ksl + t, c0 = cbase0 + 16 * nt;
-                    const f32x4 gm = load4(vg2 + c0), bt = load4(vb2 + c0);
+                    if (nt < NTH) {
+                        const f32x4 gm = load4(vg2 + c0), bt = load4(vb2 + c0);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
+                        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            xn[mt][ksl][4 * t + r] = (bf16)fmaf((acc[mt][nt][r] - mean[mt]) * rstd[mt], gm[r], bt[r]);
+                            for (int r = 0; r < 4; ++r)
+                                xn[mt][ksl][4 * t + r] = (bf16)fmaf((acc[mt][nt][r] - mean[mt]) * rstd[mt], gm[r], bt[r]);
+                    } else {   // odd KS: the empty half of the wave's last k-step
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) xn[mt][ksl][4 * t + r] = (bf16)0.f;
+                    }
                 }
         }
         // ---- MLP ---------------------------------------------------------------------------------------
@@ -702,19 +729,20 @@ __global__ __launch_bounds__(512) void tailpair_kernel(const TailBlockArgs p) {
 #pragma unroll 1
         for (int c = 0; c <= nch + 1; ++c) {
             lds_wait();               // this wave's exchange writes of the previous iteration have reached LDS
+#if !(TAIL_ABL & 8)
             lds_dma_wait_barrier();   // chunk landed, the partner's writes are visible, the other buffers are free
+#endif
             const int next_ck = I::NPC + c + 1 < nck ? I::NPC + c + 1 : 0;
             unsigned ln;
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
             const unsigned cbase = lds0 + buf * CB;
             const unsigned base = cbase + hh * (HF * 1024) + ln * 16u;
-            const unsigned xw = lds0 + I::XCH_OFF + (c & 1) * 16384 + wave * 1024 + ln * 16u;               // mine, this iteration
-            const unsigned xr = lds0 + I::XCH_OFF + ((c & 1) ^ 1) * 16384 + (wave ^ 1) * 1024 + ln * 16u;   // partner's, previous
+            const unsigned xw = lds0 + I::XCH_OFF + (c & 1) * XPAR + wave * 1024 + ln * 16u;               // mine, this iteration
+            const unsigned xr = lds0 + I::XCH_OFF + ((c & 1) ^ 1) * XPAR + (wave ^ 1) * 1024 + ln * 16u;   // partner's, previous
             const unsigned baddr = cbase + I::B1_OFF + hh * 64 + (ln >> 4) * 16u;
-            constexpr int BS = PAIR_BSM;
-            static_assert(HF % BS == 0, "fragment batches");
-            constexpr int NB = HF / BS, F1 = 2 * KSH;   // fragments [0, F1): fc1, [F1, HF): fc2
-            constexpr int BG0 = 1, BGN = 4;             // GELU batches: 8 values over BGN batches
+            constexpr int BS = KS % 2 ? PAIR_BSM_ODD : PAIR_BSM;
+            constexpr int NB = (HF + BS - 1) / BS, F1 = 2 * KSH;   // fragments [0, F1): fc1, [F1, HFM): fc2
+            constexpr int BG0 = 1, BGN = NB > 6 ? 4 : 2;   // GELU batches: 8 values over BGN batches
             constexpr int BPW = (F1 + BS - 1) / BS;     // first batch after the last fc1 fragment
             static_assert(BG0 + BGN < NB && BPW < NB && 8 % BGN == 0, "schedule");
             bf16x8 w[2][BS];
@@ -724,11 +752,15 @@ __global__ __launch_bounds__(512) void tailpair_kernel(const TailBlockArgs p) {
             lds_frags<0, BS>(base, w[0]);
             pp = lds_read_b128(xr);           // partner's partial of MY tile, chunk c - 1: [mt][r] bf16
             bi = lds_f32x4(baddr);            // fc1 biases of my tile, chunk c: the accumulators of my tile start there
-            hq = lds_read_b128(xr + 8192);    // partner's GELU half of chunk c - 2
+            hq = lds_read_b128(xr + XGELU);   // partner's GELU half of chunk c - 2
             static_for<0, NB>([&](auto b_) {
                 constexpr int b = decltype(b_)::value;
                 lds_wait();
-                if constexpr (b + 1 < NB) lds_frags<(b + 1) * BS, BS>(base, w[(b + 1) & 1]);
+#if TAIL_ABL & 16
+                if constexpr (b == 0)
+#endif
+                if constexpr (b + 1 < NB && (b + 1) * BS < I::HFM)   // used fragments only, as in the proj loop
+                    lds_frags<(b + 1) * BS, (I::HFM - (b + 1) * BS < BS ? I::HFM - (b + 1) * BS : BS)>(base, w[(b + 1) & 1]);
                 if constexpr (b < PDMAB(NB)) issue_part(b_, std::integral_constant<int, PDMAB(NB)>{}, next_ck, buf ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (b == 0) {   // fc2 operand of chunk c - 2: own half in k-slots 0..3, the partner's in 4..7
@@ -751,7 +783,7 @@ __global__ __launch_bounds__(512) void tailpair_kernel(const TailBlockArgs p) {
                         hnew[e] = (bf16)x;
                     }
                 }
-                if constexpr (b == BG0 + BGN) lds_write_b128(xw + 8192, hnew);
+                if constexpr (b == BG0 + BGN) lds_write_b128(xw + XGELU, hnew);
                 if constexpr (b == BPW) {   // fc1 partials of chunk c are complete: the partner's tile goes out as bf16
                     bf16x8 pk;
 #pragma unroll
@@ -768,7 +800,7 @@ __global__ __launch_bounds__(512) void tailpair_kernel(const TailBlockArgs p) {
                             if (ksl == 0) part[mt][t] = t == 0 ? bi : f32x4{0.f, 0.f, 0.f, 0.f};
                             mma16(w[b & 1][i], xn[mt][ksl], part[mt][t]);
                         }
-                    } else {         // fc2 of chunk c - 2
+                    } else if (fl < I::HFM) {   // fc2 of chunk c - 2
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) mma16(w[b & 1][i], hfull[mt], acc[mt][fl - F1]);
                     }
@@ -802,9 +834,17 @@ __global__ __launch_bounds__(512) void tailpair_kernel(const TailBlockArgs p) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int m = m0 + mt * 16 + lr;
-                static_assert(NTH % 2 == 0, "bf16 rows are stored as pairs of column tiles");
+                if constexpr (NTH % 2 == 1) {   // the odd column tile: 4 channels per lane
+                    constexpr int nt = NTH - 1;
+                    const int c0 = cbase0 + 16 * nt;
+                    const f32x4 gm = load4(p.gamma_n + c0), bt = load4(p.beta_n + c0);
+                    bf16x4 o;
 #pragma unroll
-                for (int nt = 0; nt < NTH; nt += 2) {
+                    for (int r = 0; r < 4; ++r) o[r] = (bf16)fmaf((acc[mt][nt][r] - mean[mt]) * rstd[mt], gm[r], bt[r]);
+                    if (m < M) *reinterpret_cast<bf16x4*>(xo + (size_t)m * p.ldn + c0) = o;
+                }
+#pragma unroll
+                for (int nt = 0; nt + 1 < NTH; nt += 2) {
                     f32x4 v[2];
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
@@ -824,6 +864,16 @@ __global__ __launch_bounds__(512) void tailpair_kernel(const TailBlockArgs p) {
 #ifndef TAIL_448_PAIR
 #define TAIL_448_PAIR 1
 #endif
+// d = 224 as wave pairs (tailpair_kernel<7, 14, NW>): built and parity-clean, but slower than the four-waves-per-SIMD kernel
+// (stand-alone, 262144 tokens: 432 us with one 8-wave workgroup per CU, 432 us with two 4-wave workgroups, against 403 us):
+// half the MFMAs per chunk barrier of the 448-wide case, 33 % more VALU instructions (partial exchange), 10 % more MFMA
+// work (the half-empty k-step).  Kept selectable for measurement.
+#ifndef TAIL_224_PAIR
+#define TAIL_224_PAIR 0
+#endif
+#ifndef TAIL_224_NW
+#define TAIL_224_NW 4
+#endif
 
 // supported widths: exactly 224 (KS 7) and 448 (KS 14), the Hiera-B+ stage-2 / stage-3 widths
 static int tail_variant(int d) {
@@ -836,7 +886,11 @@ int tailblock_chunks(int d) { return d / 8; }   // 4d hidden units in chunks of 
 size_t tailblock_image_bytes(int d) {
     const int nch = tailblock_chunks(d);
     switch (tail_variant(d)) {
+#if TAIL_224_PAIR
+        case 0: return (size_t)(PairImg<7, 14>::NPC + nch + 2) * PairImg<7, 14>::CHUNK_B;
+#else
         case 0: return (size_t)(TailImg<7, 14>::NPC + nch + 1) * TailImg<7, 14>::CHUNK_B;
+#endif
 #if TAIL_448_PAIR
         case 1: return (size_t)(PairImg<14, 28>::NPC + nch + 2) * PairImg<14, 28>::CHUNK_B;
 #else
@@ -862,8 +916,13 @@ int launch_pack_tailblock(const float* wproj, const float* bproj, const float* g
     LSAM_REQUIRE(v >= 0, LSAM_ERR_UNSUPPORTED, "pack_tailblock: width %d", d);
     char* im = static_cast<char*>(img);
     if (v == 0)
+#if TAIL_224_PAIR
+        hipLaunchKernelGGL((pack_tailpair_kernel<7, 14>), dim3(256), dim3(256), 0, s, wproj, bproj, g2, be2, w1, b1, w2,
+                           b2, d, nch, im, vec);
+#else
         hipLaunchKernelGGL((pack_tailblock_kernel<7, 14>), dim3(256), dim3(256), 0, s, wproj, bproj, g2, be2, w1, b1, w2,
                            b2, d, nch, im, vec);
+#endif
     else
 #if TAIL_448_PAIR
         hipLaunchKernelGGL((pack_tailpair_kernel<14, 28>), dim3(256), dim3(256), 0, s, wproj, bproj, g2, be2, w1, b1, w2,
@@ -895,19 +954,20 @@ template <int KS, int NTO, int MT, int NW, int WPC> static int launch_tail(const
     return LSAM_OK;
 }
 
-template <int KS, int NTO> static int launch_tailpair(const TailBlockArgs& a, hipStream_t s) {
+template <int KS, int NTO, int NW> static int launch_tailpair(const TailBlockArgs& a, hipStream_t s) {
     using I = PairImg<KS, NTO>;
-    static_assert(I::LDS_B <= 160 * 1024, "LDS budget");
-    auto kern = tailpair_kernel<KS, NTO>;
+    constexpr int LDSB = I::lds_bytes(NW), WGS = 8 / NW;
+    static_assert(WGS * LDSB <= 160 * 1024, "LDS budget");
+    auto kern = tailpair_kernel<KS, NTO, NW>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        LSAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, I::LDS_B));
+        LSAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
         attr_set = true;
     }
-    const int ngroups = cdiv(a.M, 128);
-    const int grid = ngroups < 256 ? ngroups : 256;   // persistent, one 8-wave workgroup per CU
+    const int ngroups = cdiv(a.M, 16 * NW);
+    const int grid = ngroups < 256 * WGS ? ngroups : 256 * WGS;   // persistent: 8 waves per CU in one or two workgroups
     const int rec = prof_begin(s);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), I::LDS_B, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), LDSB, s, a);
     LSAM_LAUNCH_CHECK();
     prof_end(rec, s, 18.0 * a.M * a.d * a.d, 9000 + a.d, a.M, a.d, a.d);
     return LSAM_OK;
@@ -924,17 +984,13 @@ int launch_tailblock(const TailBlockArgs& a, hipStream_t s) {
                          aligned16(a.xn_next),
                      LSAM_ERR_BAD_ARG, "tailblock: next-LayerNorm output needs gamma, beta, 16-byte alignment and ldn %% 8 == 0");
     switch (tail_variant(a.d)) {
-#if defined(TAIL_224_MT4)
-        case 0: return launch_tail<7, 14, 4, 4, 1>(a, s);
-#elif defined(TAIL_224_MT2)
-        case 0: return launch_tail<7, 14, 2, 4, 2>(a, s);
-#elif defined(TAIL_224_MT2W8)
-        case 0: return launch_tail<7, 14, 2, 8, 2>(a, s);   // 8 waves x 32 tokens: half the chunk traffic and barriers per token
+#if TAIL_224_PAIR
+        case 0: return launch_tailpair<7, 14, TAIL_224_NW>(a, s);   // wave pairs: a wave keeps 112 channels = 3 1/2 k-steps of fc1's K
 #else
-        case 0: return launch_tail<7, 14, 1, 8, 2>(a, s);    // 8 waves x 16 tokens: fits 2 waves per SIMD
+        case 0: return launch_tail<7, 14, 1, 8, 2>(a, s);    // 8 waves x 16 tokens, four waves per SIMD
 #endif
 #if TAIL_448_PAIR
-        case 1: return launch_tailpair<14, 28>(a, s);        // 8 waves, wave pairs share 32 tokens: two waves per SIMD
+        case 1: return launch_tailpair<14, 28, 8>(a, s);     // 8 waves, wave pairs share 32 tokens: two waves per SIMD
 #elif defined(TAIL_448_MT1)
         case 1: return launch_tail<14, 28, 1, 8, 1>(a, s);
 #else
