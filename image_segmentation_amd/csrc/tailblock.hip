@@ -452,6 +452,16 @@ constexpr int PDMAB(int nb) { return nb / PAIR_DMA_FRAC > 0 ? nb / PAIR_DMA_FRAC
 #ifndef PAIR_BSP
 #define PAIR_BSP 4
 #endif
+// non-temporal hints on the activation streams (bit 0: residual loads, 1: a loads, 2: out stores), so that they do not
+// evict the weight image from the XCD's L2
+#ifndef PAIR_NT
+#define PAIR_NT 0
+#endif
+#if PAIR_NT & 2
+#define PAIR_LDA(ptr) __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(ptr))
+#else
+#define PAIR_LDA(ptr) (*reinterpret_cast<const bf16x8*>(ptr))
+#endif
 #ifndef PAIR_BSM_ODD
 #define PAIR_BSM_ODD 2
 #endif
@@ -641,14 +651,20 @@ __global__ __launch_bounds__(64 * NW, 2) void tailpair_kernel(const TailBlockArg
             for (int mt = 0; mt < MT; ++mt) {
                 arow[mt] = A + (size_t)mrow[mt] * p.lda + 8 * g;
 #pragma unroll
-                for (int kl = 0; kl < 2; ++kl) afn[mt][kl] = *reinterpret_cast<const bf16x8*>(arow[mt] + 32 * kl);   // KS >= 2
+                for (int kl = 0; kl < 2; ++kl) afn[mt][kl] = PAIR_LDA(arow[mt] + 32 * kl);   // KS >= 2
             }
 #pragma unroll
             for (int nt = 0; nt < NTH; ++nt) {
                 const int c0 = cbase0 + 16 * nt;
                 const f32x4 bp = load4(vproj + c0);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = load4(p.res + (size_t)mrow[mt] * d + c0) + bp;
+                for (int mt = 0; mt < MT; ++mt) {
+#if PAIR_NT & 1
+                    acc[mt][nt] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.res + (size_t)mrow[mt] * d + c0)) + bp;
+#else
+                    acc[mt][nt] = load4(p.res + (size_t)mrow[mt] * d + c0) + bp;
+#endif
+                }
             }
             static_for<0, I::NPC>([&](auto pc_) {
                 constexpr int pc = decltype(pc_)::value;
@@ -661,7 +677,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tailpair_kernel(const TailBlockArg
                         af[mt][kl] = afn[mt][kl];
                         if constexpr (pc + 1 < I::NPC) {
                             if (2 * (pc + 1) + kl < KS)   // compile-time after unrolling; odd KS: the last chunk has one k-step
-                                afn[mt][kl] = *reinterpret_cast<const bf16x8*>(arow[mt] + 32 * (2 * (pc + 1) + kl));
+                                afn[mt][kl] = PAIR_LDA(arow[mt] + 32 * (2 * (pc + 1) + kl));
                         }
                     }
                 unsigned ln;
@@ -824,7 +840,13 @@ __global__ __launch_bounds__(64 * NW, 2) void tailpair_kernel(const TailBlockArg
             const int m = m0 + mt * 16 + lr;
             if (m < M) {
 #pragma unroll
-                for (int nt = 0; nt < NTH; ++nt) store4(p.out + (size_t)m * d + cbase0 + 16 * nt, acc[mt][nt]);
+                for (int nt = 0; nt < NTH; ++nt) {
+#if PAIR_NT & 4
+                    __builtin_nontemporal_store(acc[mt][nt], reinterpret_cast<f32x4*>(p.out + (size_t)m * d + cbase0 + 16 * nt));
+#else
+                    store4(p.out + (size_t)m * d + cbase0 + 16 * nt, acc[mt][nt]);
+#endif
+                }
             }
         }
         if (p.xn_next) {   // kernel-uniform
