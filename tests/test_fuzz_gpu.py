@@ -178,3 +178,62 @@ def test_heads_mha_random_shapes():
                 assert rel_err(got, want) < tol, (case, dt, B, nq, nk, nh, hd)
     print(f"mha sweep: {ran} ran, {refused} refused")
     assert refused * 3 <= ran
+
+
+def _random_hiera_config(rng):
+    embed, heads = rng.choice([(32, 1), (48, 1), (56, 1), (64, 2), (96, 1), (112, 2)])
+    stages = tuple(rng.randint(1, 3) for _ in range(4))
+    ends = [sum(stages[:i]) - 1 for i in range(1, 5)]
+    # a global block must not be a q-pool block (the reference itself divides by zero there)
+    cand = [i for i in range(ends[1] + 2, ends[2] + 1)]
+    glob = (rng.choice(cand),) if cand and rng.random() < 0.7 else ()
+    return dict(embed_dim=embed, num_heads=heads, stages=stages, global_att_blocks=glob,
+                window_spec=rng.choice([(8, 4, 14, 7), (8, 4, 16, 8), (4, 4, 8, 4), (8, 8, 8, 8)]))
+
+
+@pytest.mark.timeout(900)
+def test_random_hiera_configs_vs_oracle():
+    """Whole encoder (trunk + neck) forward and LoRA gradients, fp32, on Hiera configurations no golden covers: random stage
+    depths (so the two LoRA blocks land on same-width blocks, on a stage-entry block, or straddle a stage boundary), widths,
+    window specs, an optional global block, image sizes and ranks -- against the CPU oracle on the same seeded tensors.
+    Bars: FPN levels 1e-4, LoRA gradients 1e-3 (BASELINE.json)."""
+    from image_segmentation_amd._C import LsamError
+    from image_segmentation_amd.synth import synth_frames
+    from oracle import hiera_oracle as O
+    from oracle.params import make_params
+    from test_trunk_gpu import fpn_loss, make_encoder
+    rng = random.Random(2024)
+    ran = refused = 0
+    for case in range(8):
+        cfg = _random_hiera_config(rng)
+        size, rank, n = rng.choice([128, 192, 256]), rng.choice([2, 4, 8]), rng.randint(1, 2)
+        img = synth_frames(n, size, case)
+        try:
+            enc = make_encoder(cfg, rank=rank, seed=case)
+            enc.trunk.compute_dtype = torch.float32
+            out = enc(img.cuda())
+            loss = fpn_loss(out)
+            loss.backward()
+        except (LsamError, NotImplementedError) as e:
+            print("refused:", cfg, size, str(e)[:100])
+            refused += 1
+            continue
+        ran += 1
+        spec = O.block_specs(**cfg)
+        p = make_params(spec, rank, case)
+        ref = O.image_encoder_forward(p, img, spec)
+        O.fpn_loss(ref).backward()
+        for lvl, (a, b) in enumerate(zip(out["backbone_fpn"], ref["backbone_fpn"])):
+            assert a.shape == b.shape and rel_err(a, b.detach()) < 1e-4, (case, cfg, size, lvl)
+        got = {k: v.grad for k, v in enc.named_parameters() if v.requires_grad}
+        assert len(got) == 8
+        for name, g in got.items():
+            assert rel_err(g, p[name].grad) < 1e-3, (case, cfg, size, rank, name)
+        # the same configuration on bf16 operands (the bench's path): embedding bar 2e-2
+        enc.trunk.compute_dtype = torch.bfloat16
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            out16 = enc(img.cuda())
+        err16 = rel_err(out16["backbone_fpn"][2].float(), ref["backbone_fpn"][2].detach())
+        assert err16 < 2e-2, (case, cfg, size, err16)
+    print(f"hiera config sweep: {ran} ran, {refused} refused")
+    assert ran >= 5
