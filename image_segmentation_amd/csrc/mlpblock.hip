@@ -388,12 +388,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlpblock_kernel(cons
     }
 }
 
-// supported widths: d <= 64 (KS 2), d <= 128 (KS 4), d <= 224 (KS 7); d % 8 == 0
+// supported widths: d <= 64 (KS 2), d <= 128 (KS 4), d <= 144 (KS 5), d <= 224 (KS 7); d % 8 == 0
 static int mlp_variant(int d) {
     if (d % 8 != 0 || d < 16) return -1;
     if (d <= 64) return 0;
     if (d <= 112) return 1;
-    if (d > 128 && d <= 224) return 2;
+    if (d > 128 && d <= 144) return 3;   // Hiera-L stage 1 (144): 5 k-steps and 9 column tiles instead of the 224-wide 7 and 14
+    if (d > 144 && d <= 224) return 2;
     return -1;
 }
 bool mlpblock_supported(int d) { return mlp_variant(d) >= 0; }
@@ -404,6 +405,7 @@ size_t mlpblock_image_bytes(int d) {
         case 0: return (size_t)nch * MlpImg<2, 4>::CHUNK_B;
         case 1: return (size_t)nch * MlpImg<4, 7>::CHUNK_B;
         case 2: return (size_t)nch * MlpImg<7, 14>::CHUNK_B;
+        case 3: return (size_t)nch * MlpImg<5, 9>::CHUNK_B;
     }
     return 0;
 }
@@ -418,6 +420,7 @@ int launch_pack_mlpblock(const float* w1, const float* b1, const float* w2, cons
     if (v == 0) hipLaunchKernelGGL((pack_mlpblock_kernel<2, 4>), dim3(128), dim3(256), 0, s, w1, b1, w2, b2, d, nch, im, bias_p);
     if (v == 1) hipLaunchKernelGGL((pack_mlpblock_kernel<4, 7>), dim3(128), dim3(256), 0, s, w1, b1, w2, b2, d, nch, im, bias_p);
     if (v == 2) hipLaunchKernelGGL((pack_mlpblock_kernel<7, 14>), dim3(128), dim3(256), 0, s, w1, b1, w2, b2, d, nch, im, bias_p);
+    if (v == 3) hipLaunchKernelGGL((pack_mlpblock_kernel<5, 9>), dim3(128), dim3(256), 0, s, w1, b1, w2, b2, d, nch, im, bias_p);
     LSAM_LAUNCH_CHECK();
     return LSAM_OK;
 }
@@ -454,6 +457,7 @@ int launch_mlpblock(const MlpBlockArgs& a, hipStream_t s) {
         case 0: return launch_mlp<2, 4, 2, 4>(a, s);
         case 1: return launch_mlp<4, 7, 2, 4>(a, s);
         case 2: return launch_mlp<7, 14, 2, 8>(a, s);
+        case 3: return launch_mlp<5, 9, 2, 8>(a, s);
     }
     set_error("mlpblock: width %d not supported", a.d);
     return LSAM_ERR_UNSUPPORTED;

@@ -364,7 +364,7 @@ def test_fused_window_block_rejects_unsupported(ops):
         ops.window_block_pack(rnd(12 * d, 4 * d).cuda(), rnd(12 * d).cuda(), rnd(4 * d, 4 * d).cuda(), rnd(4 * d).cuda(), 8)
 
 
-@pytest.mark.parametrize("d,M", [(112, 1000), (56, 300), (224, 777), (64, 256), (160, 100)])
+@pytest.mark.parametrize("d,M", [(112, 1000), (56, 300), (224, 777), (64, 256), (160, 100), (144, 1000), (136, 130)])
 def test_fused_mlp_block(ops, d, M):
     x = rnd(M, d, seed=11)
     g2, b2 = 1 + 0.1 * rnd(d, seed=12), 0.1 * rnd(d, seed=13)
@@ -379,7 +379,7 @@ def test_fused_mlp_block(ops, d, M):
     assert torch.equal(y2, y)
 
 
-@pytest.mark.parametrize("d,M", [(112, 4096 + 17), (56, 300), (224, 777)])
+@pytest.mark.parametrize("d,M", [(112, 4096 + 17), (56, 300), (224, 777), (144, 2049)])
 def test_fused_mlp_block_with_next_norm(ops, d, M):
     """Second output of the fused MLP block: LayerNorm of its result with the next block's norm1 (hieradet.py:136)."""
     x = rnd(M, d, seed=21)
