@@ -857,6 +857,162 @@ static int attnw_launch(const AttnArgs& a, hipStream_t s) {
     return LSAM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// 4 x 4 windows (16 keys; Hiera stage 2 and its exit block: hieradet.py:56-81 with window_spec[1] = 4): one WAVE per
+// (window, head), no workgroup barrier, nothing staged but V.
+//   S^T = K Q^T : K rows and Q rows are MFMA operands as they lie in memory (lane (g, lr): token lr, channels
+//                 32 ks + 8 g .. + 7: one 16-byte global load per k-step and operand), so neither goes through LDS;
+//   softmax over the 16 keys of a query = 4 accumulator registers x the 4 lane groups (v_permlane swaps);
+//   O^T = V^T P^T: the accumulator lane (keys 4 g .. 4 g + 3 of query lr) IS the B operand if k-slot 8 g + j means key
+//                 4 g + j (j < 4, the other slots zero); V^T comes out of a wave-private row-major V tile in LDS (3.3 KB)
+//                 through the transposing read ds_read_b64_tr_b16, one read per 16 output channels.
+// The wave walks a strided list of (window, head) items (consecutive waves take the heads of one window: their
+// requests share cache lines) and asks for the next item's rows before it computes the current one.
+// Bound: HBM (qkv read once, out written once); 64-byte segments per token row and instruction: 3.5 - 3.7 TB/s measured.
+// POOLQ: the (2 x 2 max-pooled, fp32) queries come from `qpool` (4 per window).
+// ---------------------------------------------------------------------------------------------
+template <int KSD, int DT, bool POOLQ>
+__global__ __launch_bounds__(256) void attn4_fwd_kernel(const AttnArgs p, const float c_log2, const int nitems) {
+    constexpr int RBV = KSD * 64 + 16;                 // V tile row stride: conflict-free for the transposing read
+    __shared__ __attribute__((aligned(16))) char vt_all[4 * 16 * RBV];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, lr = lane & 15;
+    char* vt = vt_all + wave * 16 * RBV;
+    const int H = p.H, W = p.W, nh = p.nh, hd = p.hd, dout = nh * hd;
+    const int nwx = W >> 2, nwin = (H >> 2) * nwx;
+    const int Ho = POOLQ ? H >> 1 : H, Wo = POOLQ ? W >> 1 : W, qw = POOLQ ? 2 : 4, nq = qw * qw;
+    const bf16* __restrict__ qkv = static_cast<const bf16*>(p.qkv);
+    bf16* __restrict__ out = static_cast<bf16*>(p.out);
+    const int nwaves = gridDim.x * 4;
+
+    struct Item { uint4 k[KSD], v[KSD], q[KSD]; f32x4 qf[POOLQ ? 2 * KSD : 1]; int qtok, h; };
+    auto load_item = [&](int item, Item& it) {
+        const int wg = item / nh, h = item - wg * nh;
+        const int n = wg / nwin, win = wg - n * nwin, wy = win / nwx, wx = win - wy * nwx;
+        const size_t ktok = ((size_t)n * H + (wy * 4 + (lr >> 2))) * W + (wx * 4 + (lr & 3));
+        const bf16* kr = qkv + ktok * p.ldqkv + dout + h * hd;
+        const int qi = lr < nq ? lr : 0;
+        const size_t qtok = ((size_t)n * Ho + (wy * qw + qi / qw)) * Wo + (wx * qw + qi % qw);
+        it.qtok = lr < nq ? (int)qtok : -1;
+        it.h = h;
+#pragma unroll
+        for (int ks = 0; ks < KSD; ++ks) {
+            const int d0 = 32 * ks + 8 * g;
+            const bool ok = d0 < hd;
+            const int dc = ok ? d0 : hd - 8;            // clamped: never read past the head's channels
+            const uint4 kk = *reinterpret_cast<const uint4*>(kr + dc);
+            it.k[ks] = ok ? kk : make_uint4(0, 0, 0, 0);
+            it.v[ks] = *reinterpret_cast<const uint4*>(kr + dout + dc);   // channels >= hd: rows of O^T that are never stored
+            if constexpr (POOLQ) {
+                const float* qs = p.qpool + qtok * p.ldqp + h * hd + dc;
+                it.qf[2 * ks] = load4(qs);
+                it.qf[2 * ks + 1] = load4(qs + 4);
+            } else {
+                const uint4 qq = *reinterpret_cast<const uint4*>(qkv + qtok * p.ldqkv + h * hd + dc);
+                it.q[ks] = ok ? qq : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+
+    int item = blockIdx.x * 4 + wave;
+    if (item >= nitems) return;                         // wave-uniform; the kernel has no workgroup barrier
+    Item cur, nxt;
+    load_item(item, cur);
+#pragma unroll 1
+    for (; item < nitems; item += nwaves) {
+        const bool more = item + nwaves < nitems;       // wave-uniform
+        if (more) load_item(item + nwaves, nxt);
+        // ---- V tile -> LDS (row-major [key][channel]) --------------------------------------------------------
+#pragma unroll
+        for (int ks = 0; ks < KSD; ++ks) *reinterpret_cast<uint4*>(vt + lr * RBV + ks * 64 + g * 16) = cur.v[ks];
+        // ---- S^T = K Q^T -----------------------------------------------------------------------------------
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSD; ++ks) {
+            bf16x8 qf;
+            if constexpr (POOLQ) {
+                const bool ok = 32 * ks + 8 * g < hd;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    qf[j] = (bf16)(ok ? cur.qf[2 * ks][j] : 0.f);
+                    qf[4 + j] = (bf16)(ok ? cur.qf[2 * ks + 1][j] : 0.f);
+                }
+            } else {
+                qf = __builtin_bit_cast(bf16x8, cur.q[ks]);
+            }
+            mma16(__builtin_bit_cast(bf16x8, cur.k[ks]), qf, sc);
+        }
+        // ---- softmax over the 16 keys of query lr: registers r of the four lane groups -----------------------
+        float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+        mx = group4_max(mx);
+        float e[4], l = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            e[r] = exp2f((sc[r] - mx) * c_log2);
+            l += e[r];
+        }
+        l = group4_sum(l);
+        bf16x8 pf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pf[r] = (bf16)e[r];
+            pf[4 + r] = (bf16)0.f;
+        }
+        // ---- O^T = V^T P^T ---------------------------------------------------------------------------------
+        const float inv = 1.0f / l;
+        const bool qok = cur.qtok >= 0;
+        bf16* orow = out + (size_t)(qok ? cur.qtok : 0) * p.ldo + cur.h * hd;
+        f32x4 o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const char* a0 = vt + (4 * g + (lr >> 2)) * RBV + 32 * dt + 8 * (lr & 3);
+            const s16x4_t x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(a0));
+            const uint2 u0 = __builtin_bit_cast(uint2, x0);
+            const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(u0.x, u0.y, 0u, 0u));
+            o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma16(vf, pf, o[dt]);
+            o[dt] *= inv;
+        }
+        // lane: channels 16 dt + 4 g + r of query lr; pairs of column tiles regrouped into 16-byte stores (hd % 8 == 0)
+#pragma unroll
+        for (int dt = 0; dt + 1 < DT; dt += 2)
+            store_bf16_tile_pair(orow + 16 * dt, g, o[dt], o[dt + 1], qok && 16 * dt + 8 * g < hd);
+        if constexpr (DT % 2 == 1) {
+            if (qok && 16 * (DT - 1) + 4 * g < hd) store4(orow + 16 * (DT - 1) + 4 * g, o[DT - 1]);
+        }
+        if (p.lse && g == 0 && qok)
+            p.lse[(size_t)cur.qtok * nh + cur.h] = (mx * c_log2 + log2f(l)) * 0.69314718055994531f;
+        if (more) cur = nxt;
+    }
+}
+
+// (head_dim <= 64 with full windows of queries stays on the four-heads-per-workgroup kernel: 118 against 129 us on the B+
+// stage-2 shape; head_dim 72 .. 96: 692 against 1156 us on the Hiera-L shape; pooled queries: 172 against 189 us)
+static bool attn4_supported(const AttnArgs& a) {
+    return a.ws == 4 && a.H % 4 == 0 && a.W % 4 == 0 && a.hd % 8 == 0 && a.hd <= 96 && a.ldqkv % 8 == 0 && a.ldo % 8 == 0 &&
+           ((a.pool == 1 && a.hd > 64) || (a.pool == 2 && a.qpool));
+}
+static int attn4_launch(const AttnArgs& a, hipStream_t s) {
+    const float c = (1.0f / sqrtf((float)a.hd)) * 1.4426950408889634f;
+    const long nitems_l = (long)a.N * (a.H / 4) * (a.W / 4) * a.nh;
+    LSAM_REQUIRE(nitems_l < (1L << 31), LSAM_ERR_UNSUPPORTED, "attention: too many windows");
+    const int nitems = (int)nitems_l;
+    const int nblk = min(cdiv(nitems, 4), 256 * 8);     // strided item lists: up to 8 workgroups per CU
+    const dim3 grid(nblk), blk(256);
+#define LSAM_A4(KSD, DT)                                                                          \
+    do {                                                                                          \
+        if (a.pool == 2) hipLaunchKernelGGL((attn4_fwd_kernel<KSD, DT, true>), grid, blk, 0, s, a, c, nitems);   \
+        else hipLaunchKernelGGL((attn4_fwd_kernel<KSD, DT, false>), grid, blk, 0, s, a, c, nitems);              \
+    } while (0)
+    if (a.hd <= 64) LSAM_A4(2, 4);
+    else if (a.hd <= 80) LSAM_A4(3, 5);
+    else LSAM_A4(3, 6);
+#undef LSAM_A4
+    LSAM_LAUNCH_CHECK();
+    return LSAM_OK;
+}
+
 // head_dim 65..96 (Hiera-L 72, Hiera-T/S 96): the same streaming kernel on 256-byte tile rows, two query tiles per wave
 static int attn2_wide_launch(const AttnArgs& a, int max_nq, hipStream_t s) {
     const WinGeom G = make_geom(a.H, a.W, a.ws, a.pool);
@@ -917,6 +1073,7 @@ template <typename T> int launch_attn_fwd(const AttnArgs& a, hipStream_t s) {
     ProfScope ps(s, 4.0 * a.N * (a.H / a.pool) * (a.W / a.pool) * (double)(G.wsh * G.wsw) * a.nh * a.hd,
                  a.ws == 0 ? PROF_ATTN_GLOBAL : PROF_ATTN_WIN, a.N * (a.H / a.pool) * (a.W / a.pool), G.wsh * G.wsw, a.nh * a.hd);
     if constexpr (sizeof(T) == 2) {
+        if (attn4_supported(a)) return attn4_launch(a, s);   // 4 x 4 windows: one wave per (window, head), V alone through LDS
         if (a.bias_t && a.hd <= 64 && a.ws > 0 && G.wsh * G.wsw > 64 && G.wsh * G.wsw <= 208 && max_nq > 64 && a.ldqkv % 8 == 0)
             return attnw_launch(a, s);   // (pooled windows have few queries per staged K/V tile: the streaming kernel below)
         // (not for a forward that feeds the backward: this kernel rounds the PRE-SCALED queries to bf16, so its log-sum-exp

@@ -292,7 +292,10 @@ def test_attention_fwd_with_pooled_queries(ops, dt, H, ws, nh):
     poisoned = qkv.clone()
     poisoned[..., :d] = float("nan")
     got, lse = ops.attention_fwd(poisoned, bias, ws, 2, nh, want_lse=True, q_pooled=qp)
-    assert torch.equal(got, want) and torch.equal(lse, lse_want)
+    if ws == 4 and dt == torch.bfloat16:   # 4 x 4 windows with pooled queries run the one-wave-per-window kernel: same math, other order
+        assert rel_err(got.float(), want.float()) < 6e-3 and rel_err(lse, lse_want) < 1e-5
+    else:
+        assert torch.equal(got, want) and torch.equal(lse, lse_want)
 
 
 def test_maxpool_cast_im2col(ops):
