@@ -279,6 +279,18 @@ class SAM2Base(nn.Module):
         self.compute_dtype: Optional[torch.dtype] = torch.float32   # the heads are ~1 % of the FLOPs: exact-fp32 MFMA by default
         self._packs = _PackCache()
         self._dense_pe = {}
+        # packed weights are keyed by (data_ptr, _version); checkpoint loaders that write through `.data` do not bump the
+        # version, so a load drops every packed image (as Hiera.invalidate_packed does for the trunk)
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed())
+
+    def invalidate_packed(self):
+        """Drop the packed head weights and the cached dense positional encoding (call after editing parameters through
+        `.data`; `load_state_dict` does it by itself).  The attached image encoder has its own `invalidate_packed`."""
+        self._packs = _PackCache()
+        self._dense_pe = {}
+        for m in (getattr(self.image_encoder, "trunk", None), getattr(self.image_encoder, "neck", None)):
+            if m is not None and hasattr(m, "invalidate_packed"):
+                m.invalidate_packed()
 
     # -- sam2_base.py:467-479 ------------------------------------------------------------------------------------
     def forward_image(self, img_batch: torch.Tensor):

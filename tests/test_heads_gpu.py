@@ -261,3 +261,55 @@ def test_heads_fail_loudly_without_gpu_tensors():
         m._forward_sam_heads(torch.zeros(1, 256, 64, 64), None, None, [torch.zeros(1, 32, 256, 256), torch.zeros(1, 64, 128, 128)])
     with pytest.raises(LsamError):
         m.forward_image(torch.zeros(1, 3, 1024, 1024).cuda())
+
+
+def test_decoder_lora_training_steps_refresh_packed_weights():
+    """The heads keep packed copies of their weights keyed by (data_ptr, _version): optimizer steps on the decoder LoRA
+    factors must be seen by the next forward, `load_state_dict` drops every packed image, and an edit through `.data`
+    (which does not bump the version) is picked up after `invalidate_packed()`."""
+    from image_segmentation_amd.sam_heads import wrap_decoder_lora
+    B = 1
+    fpn = _synthetic_fpn(B, seed=5)
+    coords, labels = torch.tensor([[[400.0, 700.0]]]), torch.ones(B, 1, dtype=torch.int32)
+
+    def fresh_copy(src):
+        m2, hp2 = _make_heads(4)
+        wrap_decoder_lora(m2, 4)
+        m2.load_state_dict(src.state_dict(), strict=True)
+        return m2, hp2
+
+    m, hp = _make_heads(4)
+    wrap_decoder_lora(m, 4)
+    for n, p in m.named_parameters():          # train_lora_sam.py:116-117 freezes everything but the LoRA factors
+        p.requires_grad = ".A_" in n or ".B_" in n
+    lora = [p for p in m.parameters() if p.requires_grad]
+    assert len(lora) == 8
+    gen = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for p in lora:
+            p.copy_(0.05 * torch.randn(p.shape, generator=gen))
+    opt = torch.optim.SGD(lora, lr=0.5)
+    outs = []
+    for _ in range(3):
+        out = _run_product(m, hp, fpn, coords, labels)
+        outs.append(out["low_res_multimasks"].detach().clone())
+        (out["low_res_multimasks"] ** 2).mean().backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])       # every step was seen
+    after = _run_product(m, hp, fpn, coords, labels)["low_res_multimasks"].detach()
+    m2, hp2 = fresh_copy(m)                                                               # same parameters, nothing cached
+    assert torch.equal(after, _run_product(m2, hp2, fpn, coords, labels)["low_res_multimasks"].detach())
+    # load_state_dict into a model that has already packed: the old images must not survive
+    m3, hp3 = _make_heads(4)
+    wrap_decoder_lora(m3, 4)
+    _run_product(m3, hp3, fpn, coords, labels)
+    m3.load_state_dict(m.state_dict(), strict=True)
+    assert torch.equal(after, _run_product(m3, hp3, fpn, coords, labels)["low_res_multimasks"].detach())
+    # an edit through .data is invisible until invalidate_packed()
+    w = m3.sam_mask_decoder.transformer.layers[0].self_attn.B_q.weight
+    w.data.mul_(-1.0)
+    stale = _run_product(m3, hp3, fpn, coords, labels)["low_res_multimasks"].detach()
+    m3.invalidate_packed()
+    seen = _run_product(m3, hp3, fpn, coords, labels)["low_res_multimasks"].detach()
+    assert torch.equal(stale, after) and not torch.equal(seen, after)
