@@ -603,11 +603,14 @@ template <int OFF, typename V> __device__ __forceinline__ void g3_rd(unsigned ad
 
 // NGUARD: N need not be a multiple of 224 (Hiera-L widths, multiples of 144): W rows >= N are zero-filled by the DMA's
 // range check and every epilogue access is guarded by its column.
-template <bool OUTF32, bool POOL, bool NGUARD = false>
+// NT = column tiles per wave: 7 (224-wide output tiles) or 6 (192-wide: N = 576, 1152, 1728, 2304 ... of Hiera-L divide by 192
+// and not by 224, so the narrower tile wastes no MFMAs on guard columns).
+template <bool OUTF32, bool POOL, bool NGUARD = false, int NT = 7>
 __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
     static_assert(!(POOL && NGUARD), "pooled epilogue needs N % 224 == 0");
+    static_assert(NT == 7 || (NT == 6 && !POOL && !NGUARD), "192-wide tiles: plain epilogues, N % 192 == 0");
     using T = bf16;
-    constexpr int MT = 4, NT = 7, BM = 256, BN = 224, NW = 8, BK = 64, A_IT = 4;
+    constexpr int MT = 4, BM = 256, BN = 32 * NT, WNC = 16 * NT, NW = 8, BK = 64, A_IT = 4;   // WNC: columns per wave
     constexpr int STAGE = 65536;       // 512 rows x 128 B; rows 480..511 only take the padding DMA pieces
     constexpr int BIAS0 = 2 * STAGE;   // 4 x 1 KiB: fp32 bias slice [224] of a tile, slot = tile count & 3
 
@@ -683,11 +686,11 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
             const unsigned vo = (kok && (!NGUARD || ta.wrow0 + 64 * i < N)) ? ta.woff0 + i * wstep + kb : 0xFFFFFFFFu;   // N % 224 == 0: every W row exists
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(base + (32 + wave + NW * i) * 1024), 16, vo, 0, 0, 0);
         }
-        if (wave < 4) {
+        if (NT == 7 && wave < 4) {
             const unsigned vo = (kok && (!NGUARD || ta.wrow0 + 192 < N)) ? ta.woff0 + 3 * wstep + kb : 0xFFFFFFFFu;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(base + (32 + wave + NW * 3) * 1024), 16, vo, 0, 0, 0);
         } else if (wave == 4 && kt == 0) {
-            const unsigned vo = lane < 56 ? (unsigned)(ta.n0 + 4 * lane) * 4u : 0xFFFFFFFFu;
+            const unsigned vo = lane < 8 * NT ? (unsigned)(ta.n0 + 4 * lane) * 4u : 0xFFFFFFFFu;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_ptr_t)(smem + BIAS0 + bslot * 1024), 16, vo, 0, 0, 0);
         } else {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_ptr_t)(base + (32 + wave + NW * 3) * 1024), 16, 0xFFFFFFFFu, 0, 0, 0);
@@ -711,11 +714,11 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
             const unsigned vo = (kok && (!NGUARD || ta.wrow0 + 64 * i < N)) ? ta.woff0 + i * wstep + kb : 0xFFFFFFFFu;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(base + (32 + wave + NW * i) * 1024), 16, vo, 0, 0, 0);
         } else {
-            if (wave < 4) {
+            if (NT == 7 && wave < 4) {
                 const unsigned vo = (kok && (!NGUARD || ta.wrow0 + 192 < N)) ? ta.woff0 + 3 * wstep + kb : 0xFFFFFFFFu;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lds_ptr_t)(base + (32 + wave + NW * 3) * 1024), 16, vo, 0, 0, 0);
             } else if (wave == 4 && kt == 0) {
-                const unsigned vo = lane < 56 ? (unsigned)(ta.n0 + 4 * lane) * 4u : 0xFFFFFFFFu;
+                const unsigned vo = lane < 8 * NT ? (unsigned)(ta.n0 + 4 * lane) * 4u : 0xFFFFFFFFu;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_ptr_t)(smem + BIAS0 + bslot * 1024), 16, vo, 0, 0, 0);
             } else {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_ptr_t)(base + (32 + wave + NW * 3) * 1024), 16, 0xFFFFFFFFu, 0, 0, 0);
@@ -726,7 +729,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
     // per-lane fragment read addresses in stage 0 (k-step 1 is chunk ^ 4 of k-step 0)
     const unsigned chunk0 = (unsigned)((g ^ (lr & 7)) << 4);
     const unsigned aA0 = lds0 + (unsigned)(wm * 64 + lr) * 128u + chunk0, aA1 = aA0 ^ 64u;
-    const unsigned aW0 = lds0 + (unsigned)(BM + wn * 112 + lr) * 128u + chunk0, aW1 = aW0 ^ 64u;
+    const unsigned aW0 = lds0 + (unsigned)(BM + wn * WNC + lr) * 128u + chunk0, aW1 = aW0 ^ 64u;
 
     // Fragments are held as 4 x u32 and re-typed at the MFMA: as <8 x bf16> values carried round the loop hipcc
     // re-packs some of them element by element (v_lshrrev / v_perm) at the loop head, i.e. BEFORE the counted wait
@@ -755,7 +758,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
     auto epilogue = [&](int m0, int n0) {
         int lr = lr_c, g = g_c;
         asm volatile("" : "+v"(lr), "+v"(g));
-        const int nc = n0 + wn * 112 + 4 * g;
+        const int nc = n0 + wn * WNC + 4 * g;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             __builtin_amdgcn_sched_barrier(0);
@@ -764,9 +767,9 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
             const int mc = mok ? m : M - 1;
             // NGUARD: column c of this wave's 112 is inside the matrix while c < nlim (N % 8 == 0: a 16- or 8-byte store
             // is inside or outside as a whole)
-            const int nlim = NGUARD ? N - (n0 + wn * 112) : 112;
+            const int nlim = NGUARD ? N - (n0 + wn * WNC) : WNC;
             auto store_row = [&](auto* base, int ld, const f32x4 (&val)[NT]) {
-                auto* rowp = base + (size_t)mc * ld + n0 + wn * 112;
+                auto* rowp = base + (size_t)mc * ld + n0 + wn * WNC;
                 if constexpr (sizeof(*base) == 4) {
                     if (mok) {
 #pragma unroll
@@ -777,7 +780,9 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
 #pragma unroll
                     for (int nt = 0; nt + 1 < NT; nt += 2)
                         store_bf16_tile_pair(rowp + nt * 16, g, val[nt], val[nt + 1], mok && (!NGUARD || nt * 16 + 8 * g < nlim));
-                    if (mok && (!NGUARD || (NT - 1) * 16 + 4 * g < nlim)) store4(rowp + (NT - 1) * 16 + 4 * g, val[NT - 1]);
+                    if constexpr (NT % 2 == 1) {
+                        if (mok && (!NGUARD || (NT - 1) * 16 + 4 * g < nlim)) store4(rowp + (NT - 1) * 16 + 4 * g, val[NT - 1]);
+                    }
                 }
             };
             const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -818,7 +823,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
         asm volatile("" : "+v"(lr), "+v"(g));
         const int tm = t / tiles_n, n0 = (t % tiles_n) * BN;
         const int pn = tm / (ptx * pty), py0 = ((tm / ptx) % pty) * pTH, px0 = (tm % ptx) * pTW;
-        const int nc = n0 + wn * 112 + 4 * g;
+        const int nc = n0 + wn * WNC + 4 * g;
         const int hh = p.pool_h >> 1, hw = p.pool_w >> 1;
 #pragma unroll
         for (int mp = 0; mp < 2; ++mp) {
@@ -882,10 +887,10 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
                 // would put a vmcnt(0) in front of every tile)
                 unsigned ln;
                 asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-                const unsigned ab = lds0 + BIAS0 + (unsigned)(wn * 112) * 4u + (ln >> 4) * 16u + (unsigned)(it & 3) * 1024u;
+                const unsigned ab = lds0 + BIAS0 + (unsigned)(wn * WNC) * 4u + (ln >> 4) * 16u + (unsigned)(it & 3) * 1024u;
                 g3_static_for<0, NT>([&](auto i_) { g3_rd<decltype(i_)::value * 64>(ab, acc[0][decltype(i_)::value]); });
                 rd_set(aA1 + so, aW1 + so, af1, wf1);
-                asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -898,7 +903,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
                 }
             } else {
                 rd_set(aA1 + so, aW1 + so, af1, wf1);
-                asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 mfmas(af0, wf0);
             }
@@ -906,7 +911,9 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
             // the next k-tile has landed (this wave's pieces; the barrier covers the others') and every wave is
             // done reading this stage
             if (kt == 0 && after >= 24) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (kt == 0 && after >= 20) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else if (kt == 0 && after >= 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (kt == 0 && after >= 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             rd_set(aA0 + sn, aW0 + sn, af0, wf0);
@@ -923,7 +930,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
                     if (live) issue_piece(da, dkt, dstage, dit & 3, c_);
                     if (mm) {
 #pragma unroll
-                        for (int e = (28 * c) / 8; e < (28 * (c + 1)) / 8; ++e) {
+                        for (int e = (MT * NT * c) / 8; e < (MT * NT * (c + 1)) / 8; ++e) {
                             const int nt = e / MT, mt = e % MT;
                             mma16(__builtin_bit_cast(bf16x8, wf1[nt]), __builtin_bit_cast(bf16x8, af1[mt]), acc[mt][nt]);
                         }
@@ -955,8 +962,8 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
             after = 12;   // 14 stores; counted a little short so that a store the compiler fuses or drops cannot matter
         } else {
             epilogue(m0, n0);
-            // full tile: 28 (fp32) / 16 (bf16) stores, counted short; a partial tile issues fewer: wait for everything
-            after = (m0 + BM <= M && (!NGUARD || n0 + BN <= N)) ? (OUTF32 ? 24 : 12) : 0;
+            // full tile: 28 (fp32) / 16 (bf16) stores (NT = 6: 24 / 12), counted short; a partial tile issues fewer: wait for everything
+            after = (m0 + BM <= M && (!NGUARD || n0 + BN <= N)) ? (NT == 7 ? (OUTF32 ? 24 : 12) : (OUTF32 ? 20 : 8)) : 0;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1066,20 +1073,20 @@ template <typename T, int WN, bool OUTF32, bool POOL = false> static int launch_
     return LSAM_OK;
 }
 
-template <bool OUTF32, bool POOL = false, bool NGUARD = false> static int launch_v3(const GemmArgs& a, hipStream_t s) {
+template <bool OUTF32, bool POOL = false, bool NGUARD = false, int NT = 7> static int launch_v3(const GemmArgs& a, hipStream_t s) {
     constexpr int LDS = 2 * 65536 + 4096;
-    auto kern = gemm3_kernel<OUTF32, POOL, NGUARD>;
+    auto kern = gemm3_kernel<OUTF32, POOL, NGUARD, NT>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         LSAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
-    const int ntiles = cdiv(a.M, 256) * cdiv(a.N, 224);
+    const int ntiles = cdiv(a.M, 256) * cdiv(a.N, 32 * NT);
     const int nblk = ntiles < 256 ? ntiles : 256;   // persistent: one workgroup per CU
     const int rec = prof_begin(s);
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), LDS, s, a);
     LSAM_LAUNCH_CHECK();
-    prof_end(rec, s, 2.0 * a.M * a.N * a.K, 2000 + 224 + (OUTF32 ? 1 : 0) + (NGUARD ? 2 : 0), a.M, a.N, a.K);
+    prof_end(rec, s, 2.0 * a.M * a.N * a.K, 2000 + 224 + (OUTF32 ? 1 : 0) + (NGUARD || NT == 6 ? 2 : 0), a.M, a.N, a.K);
     return LSAM_OK;
 }
 
@@ -1252,6 +1259,12 @@ template <typename T> int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
             (!(a.flags & LSAM_EPI_SAVE_PRE) || (a.ldo2 % 8 == 0 && aligned16(a.out2))) &&
             (!(a.flags & LSAM_EPI_GELU_BWD) || a.ldaux % 4 == 0) && (!a.res || a.ldres % 4 == 0)) {
             const bool of32 = (a.flags & LSAM_EPI_OUT_F32) != 0;
+#ifndef GEMM3_NT6
+#define GEMM3_NT6 1
+#endif
+            // N a multiple of 192 (Hiera-L stages 3 / 4: 576, 1152, 1728, 2304, 3456, 4608): 192-wide tiles, no guard columns
+            // (unless the 224-wide tiling wastes under 3 % of its columns: 4608 -> 2.1 %, where the wider tile is 2 % faster)
+            if (GEMM3_NT6 && a.N % 192 == 0 && (long)(cdiv(a.N, 224) * 224 - a.N) * 100 >= 3L * a.N) return of32 ? launch_v3<true, false, false, 6>(a, s) : launch_v3<false, false, false, 6>(a, s);
             return of32 ? launch_v3<true, false, true>(a, s) : launch_v3<false, false, true>(a, s);
         }
     }

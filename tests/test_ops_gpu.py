@@ -67,7 +67,9 @@ def test_linear_persistent_many_tiles(ops, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(33000, 432, 144), (20000, 576, 144), (5000, 288, 288), (70000, 144, 576), (9000, 1152, 288),
-                                   (1100, 3456, 1184), (2000, 152, 64), (40000, 864, 320), (1500, 96 * 3, 96)])
+                                   (1100, 3456, 1184), (2000, 152, 64), (40000, 864, 320), (1500, 96 * 3, 96),
+                                   # N % 192 == 0: the 192-wide tile variant (no guard columns), incl. half k-tiles and ragged M
+                                   (33000, 576, 224), (5000, 1728, 576), (2049, 192, 96), (70000, 384, 480), (66000, 768, 32)])
 def test_linear_column_guarded_tiles(ops, M, N, K):
     """bf16, N NOT a multiple of 224 (Hiera-L widths are multiples of 144, Hiera-T/S of 96): the 256 x 224 persistent kernel
     with zero-filled weight rows and column-guarded epilogues -- every epilogue flavour, ragged M, K tails, and a poisoned
