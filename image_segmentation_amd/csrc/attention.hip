@@ -987,6 +987,131 @@ __global__ __launch_bounds__(256) void attn4_fwd_kernel(const AttnArgs p, const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 8 x 8 windows, head_dim 72 .. 96 (Hiera-L / S / T stage 1, whose widths the fused stage-1 kernel does not take): the same
+// scheme on 64 keys and 64 queries -- one wave per (window, head), K and Q fragments straight from memory (4 token tiles
+// x KSD k-steps each), V through a wave-private row-major LDS tile (64 x 208 B) and the transposing read.  All 16 score
+// tiles are formed first (K and Q die), then per query tile: softmax over its 64 keys (16 registers x 4 lane groups),
+// O^T = V^T P^T with k-slot 8 g + 4 t + r meaning key 32 u + 16 t + 4 g + r, store.  No prefetch across items: two waves
+// per SIMD in different phases keep the loads flowing.  HBM-bound like the 4 x 4 kernel.
+// ---------------------------------------------------------------------------------------------
+#ifndef ATTN8_WGS
+#define ATTN8_WGS 2   // workgroups per CU (52 KiB of LDS, 170 registers each; 3 is slower: 333 against 285 us)
+#endif
+template <int KSD, int DT>
+__global__ __launch_bounds__(256, ATTN8_WGS) void attn8_fwd_kernel(const AttnArgs p, const float c_log2, const int nitems) {
+    constexpr int RBV = KSD * 64 + 16;
+    __shared__ __attribute__((aligned(16))) char vt_all[4 * 64 * RBV];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, lr = lane & 15;
+    char* vt = vt_all + wave * 64 * RBV;
+    const int H = p.H, W = p.W, nh = p.nh, hd = p.hd, dout = nh * hd;
+    const int nwx = W >> 3, nwin = (H >> 3) * nwx;
+    const bf16* __restrict__ qkv = static_cast<const bf16*>(p.qkv);
+    bf16* __restrict__ out = static_cast<bf16*>(p.out);
+    const int nwaves = gridDim.x * 4;
+#pragma unroll 1
+    for (int item = blockIdx.x * 4 + wave; item < nitems; item += nwaves) {
+        const int wg = item / nh, h = item - wg * nh;
+        const int n = wg / nwin, win = wg - n * nwin, wy = win / nwx, wx = win - wy * nwx;
+        size_t tok[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {   // token 16 tt + lr of the window: row 2 tt + (lr >> 3), column lr & 7
+            tok[tt] = ((size_t)n * H + (wy * 8 + 2 * tt + (lr >> 3))) * W + (wx * 8 + (lr & 7));
+        }
+        uint4 kf[4][KSD], qf[4][KSD];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int ks = 0; ks < KSD; ++ks) {
+                const int d0 = 32 * ks + 8 * g;
+                const bool ok = d0 < hd;
+                const bf16* row = qkv + tok[tt] * p.ldqkv + h * hd + (ok ? d0 : hd - 8);   // clamped: never past the head's channels
+                const uint4 vv = *reinterpret_cast<const uint4*>(row + 2 * dout);
+                const uint4 kk = *reinterpret_cast<const uint4*>(row + dout);
+                const uint4 qq = *reinterpret_cast<const uint4*>(row);
+                *reinterpret_cast<uint4*>(vt + (16 * tt + lr) * RBV + ks * 64 + g * 16) = vv;   // channels >= hd: rows of O^T never stored
+                kf[tt][ks] = ok ? kk : make_uint4(0, 0, 0, 0);
+                qf[tt][ks] = ok ? qq : make_uint4(0, 0, 0, 0);
+            }
+        // ---- S^T[key tile][query tile] -----------------------------------------------------------------------
+        f32x4 sc[4][4];   // [qt][kt]
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                sc[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KSD; ++ks)
+                    mma16(__builtin_bit_cast(bf16x8, kf[kt][ks]), __builtin_bit_cast(bf16x8, qf[qt][ks]), sc[qt][kt]);
+            }
+        // ---- V^T fragments (shared by the four query tiles) ----------------------------------------------------
+        bf16x8 vf[DT][2];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const char* a0 = vt + (32 * u + 4 * g + (lr >> 2)) * RBV + 32 * dt + 8 * (lr & 3);
+                const s16x4_t x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(a0));
+                const s16x4_t x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(a0 + 16 * RBV));
+                const uint2 u0 = __builtin_bit_cast(uint2, x0), u1 = __builtin_bit_cast(uint2, x1);
+                vf[dt][u] = __builtin_bit_cast(bf16x8, make_uint4(u0.x, u0.y, u1.x, u1.y));
+            }
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[qt][kt][r]);
+            mx = group4_max(mx);
+            float l = 0.f;
+            bf16x8 pf[2];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = exp2f((sc[qt][kt][r] - mx) * c_log2);
+                    l += e;
+                    pf[kt >> 1][4 * (kt & 1) + r] = (bf16)e;
+                }
+            l = group4_sum(l);
+            const float inv = 1.0f / l;
+            f32x4 o[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                mma16(vf[dt][0], pf[0], o[dt]);
+                mma16(vf[dt][1], pf[1], o[dt]);
+                o[dt] *= inv;
+            }
+            bf16* orow = out + tok[qt] * p.ldo + h * hd;
+#pragma unroll
+            for (int dt = 0; dt + 1 < DT; dt += 2) store_bf16_tile_pair(orow + 16 * dt, g, o[dt], o[dt + 1], 16 * dt + 8 * g < hd);
+            if constexpr (DT % 2 == 1) {
+                if (16 * (DT - 1) + 4 * g < hd) store4(orow + 16 * (DT - 1) + 4 * g, o[DT - 1]);
+            }
+            if (p.lse && g == 0) p.lse[tok[qt] * nh + h] = (mx * c_log2 + log2f(l)) * 0.69314718055994531f;
+        }
+    }
+}
+static bool attn8_supported(const AttnArgs& a) {
+    return a.ws == 8 && a.pool == 1 && a.H % 8 == 0 && a.W % 8 == 0 && a.hd % 8 == 0 && a.hd > 64 && a.hd <= 96 && a.ldqkv % 8 == 0 &&
+           a.ldo % 8 == 0;   // (the scores are formed from the unscaled bf16 q and k, as the backward recomputes them: the LSE is consistent)
+}
+static int attn8_launch(const AttnArgs& a, hipStream_t s) {
+    const float c = (1.0f / sqrtf((float)a.hd)) * 1.4426950408889634f;
+    const long nitems_l = (long)a.N * (a.H / 8) * (a.W / 8) * a.nh;
+    LSAM_REQUIRE(nitems_l < (1L << 31), LSAM_ERR_UNSUPPORTED, "attention: too many windows");
+    const int nitems = (int)nitems_l;
+    const dim3 grid(min(cdiv(nitems, 4), 256 * ATTN8_WGS)), blk(256);
+    if (a.hd <= 80) hipLaunchKernelGGL((attn8_fwd_kernel<3, 5>), grid, blk, 0, s, a, c, nitems);
+    else hipLaunchKernelGGL((attn8_fwd_kernel<3, 6>), grid, blk, 0, s, a, c, nitems);
+    LSAM_LAUNCH_CHECK();
+    return LSAM_OK;
+}
+
 // (head_dim <= 64 with full windows of queries stays on the four-heads-per-workgroup kernel: 118 against 129 us on the B+
 // stage-2 shape; head_dim 72 .. 96: 692 against 1156 us on the Hiera-L shape; pooled queries: 172 against 189 us)
 static bool attn4_supported(const AttnArgs& a) {
@@ -1073,7 +1198,8 @@ template <typename T> int launch_attn_fwd(const AttnArgs& a, hipStream_t s) {
     ProfScope ps(s, 4.0 * a.N * (a.H / a.pool) * (a.W / a.pool) * (double)(G.wsh * G.wsw) * a.nh * a.hd,
                  a.ws == 0 ? PROF_ATTN_GLOBAL : PROF_ATTN_WIN, a.N * (a.H / a.pool) * (a.W / a.pool), G.wsh * G.wsw, a.nh * a.hd);
     if constexpr (sizeof(T) == 2) {
-        if (attn4_supported(a)) return attn4_launch(a, s);   // 4 x 4 windows: one wave per (window, head), V alone through LDS
+        if (attn4_supported(a)) return attn4_launch(a, s);
+        if (attn8_supported(a)) return attn8_launch(a, s);   // 8 x 8 windows, head_dim 72 .. 96: the same scheme on 64 keys   // 4 x 4 windows: one wave per (window, head), V alone through LDS
         if (a.bias_t && a.hd <= 64 && a.ws > 0 && G.wsh * G.wsw > 64 && G.wsh * G.wsw <= 208 && max_nq > 64 && a.ldqkv % 8 == 0)
             return attnw_launch(a, s);   // (pooled windows have few queries per staged K/V tile: the streaming kernel below)
         // (not for a forward that feeds the backward: this kernel rounds the PRE-SCALED queries to bf16, so its log-sum-exp
