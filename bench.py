@@ -2,7 +2,11 @@
 """Throughput of the LoRA-SAM2 Hiera image-encoder hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W [--config 1|3|4]
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N>1 either way: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+  bench.py --gpus N ...` (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or plain
+  `python bench.py --gpus N`, which starts exactly that launcher as a CHILD process before anything touches the GPU and
+  relays rank 0's line.  Under the launcher a process group is built for ANY N, so `--nproc-per-node 1` runs the whole
+  RCCL exchange step (broadcast + per-LoRA-block all-reduces from inside the backward) on one GPU.
 
 --config 1 (default; BASELINE.json configs[1], and configs[2] under --gpus 8): sam2.1_hiera_base_plus + LoRA_qkv r=4,
     bf16 fwd+bwd, 16 frames of 1024^2 per GPU.  One step = SAM2Base.forward_image (sam2_base.py:467-479: trunk + FPN neck +
@@ -23,6 +27,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 import types
@@ -38,7 +44,12 @@ PEAK_HBM_GBS = 8000.0        # HBM3E spec (same table; ~6.3 TB/s is what a strea
 BPLUS = dict(embed_dim=112, num_heads=2)
 LARGE = dict(embed_dim=144, num_heads=2, stages=(2, 6, 36, 4), global_att_blocks=(23, 33, 43), window_spec=(8, 4, 16, 8))
 # algorithmic FLOPs per 1024^2 frame
-GF_BPLUS_FWD_BWD = 657.4e9   # Hiera-B+ r=4 forward + LoRA backward
+GF_BPLUS_FWD_BWD = 657.4e9   # Hiera-B+ r=4 forward + LoRA backward, neck lateral convs as the reference executes them
+# forward_image composes conv_s0 / conv_s1 into the level-0 / 1 lateral convs (sam2_base.py:473-478 after
+# image_encoder.py:112-114): 2*65536*112*32 + 2*16384*224*64 = 0.94 GF instead of 2*65536*112*256 + 2*16384*224*256 = 5.64 GF,
+# and the reference's own conv_s0 / conv_s1 (2*65536*256*32 + 2*16384*256*64 = 1.61 GF, outside SURVEY's 657.4) never run.
+# The whole-step fraction is priced on what this implementation must compute: 657.4 - 5.64 + 0.94.
+GF_BPLUS_FWD_BWD_COMPOSED = GF_BPLUS_FWD_BWD - 5.64e9 + 0.94e9
 GF_BPLUS_FWD = 621.3e9       # forward incl. neck (7.05 GF); the trunk-only extraction pass is 614.2
 GF_BPLUS_TRUNK = 614.2e9
 GF_LARGE_FWD = 1821.4e9      # Hiera-L r=8 forward incl. neck
@@ -203,16 +214,28 @@ def main():
                          "prompt encoder + mask decoder (fp32 operands), MultiStepMultiMasksAndIous, backward through all of it")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ      # under torch.distributed.run
+    if not launched and args.gpus > 1:
+        # Plain `python bench.py --gpus N`: start the N workers ourselves, as a child process, BEFORE this process makes any
+        # GPU call (importing torch makes none); the child's rank 0 prints the line on the stdout we share.
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    rank = int(os.environ.get("RANK", "0")) if launched else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if launched:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=device)
+        dist.init_process_group(backend="nccl", device_id=device)    # backend "nccl" IS RCCL on ROCm (train_lora_sam.py:32)
+    grouped = launched
 
     from image_segmentation_amd import _C
     from image_segmentation_amd.dp import LoRAGradReducer
@@ -239,7 +262,7 @@ def main():
         img = synth_frames_device(B, 1024, 0, device, first_index=rank * B)   # resident before timing
         steps = args.steps if args.steps is not None else 20
         frames_per_step = B
-        gf_per_frame = GF_BPLUS_FWD_BWD
+        gf_per_frame = GF_BPLUS_FWD_BWD if args.plain_encoder else GF_BPLUS_FWD_BWD_COMPOSED
 
         if args.heads:
             from image_segmentation_amd.loss_fns import CORE_LOSS_KEY, MultiStepMultiMasksAndIous
@@ -295,7 +318,7 @@ def main():
             return f[0, 0]
 
     def fence():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -307,10 +330,11 @@ def main():
         last = step(i)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    collectives = dict(reducer.stats) if config == 1 else None      # issued during warm-up + timed steps
     assert torch.isfinite(last).item(), "non-finite result"
     fps = world * frames_per_step * steps / elapsed
 
@@ -322,10 +346,16 @@ def main():
         # those launches / their duration.
         psteps = min(2, steps)
         _C.check(_C.lib().lsam_prof_arm(600 * psteps))
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
         for i in range(psteps):
             step(i)
         torch.cuda.synchronize()
+        prof_wall_ms = 1e3 * (time.perf_counter() - tp0) / psteps
         kernels, agg = kernel_table(psteps)
+        bracket = C.c_float(0.0)
+        _C.check(_C.lib().lsam_prof_bracket_cost(_C.stream(), 200, C.byref(bracket)))
+        n_launch = sum(a[0] for a in agg.values()) / psteps
         mfma_rows = [r for r in kernels if r["unit"] == "TFLOP/s"]
         dom = max(mfma_rows, key=lambda r: r["ms_per_step"])
         cnt, tms, twk = agg[dom["cfg"]]
@@ -334,10 +364,17 @@ def main():
                     "unit": "TFLOP/s", "frac": dom["frac"], "traffic": measured_traffic(traffic_key),
                     "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"],
                     "avg_launch_gflop": round(twk / cnt / 1e9, 3), "kernel_ms_per_step": dom["ms_per_step"],
-                    "all_timed_kernel_ms_per_step": round(sum(r["ms_per_step"] for r in kernels), 3)}
+                    # Sum of every liblsam launch's event bracket.  A bracket spans the kernel plus the stream's cost of the two
+                    # event packets, so the raw sum can exceed a step's wall time; `empty_bracket_us` (lsam_prof_bracket_cost:
+                    # the same event pair around nothing) is that cost, and the `_net` sum has it subtracted per launch.  The
+                    # bracketed steps themselves run slower than the timed ones (`profiled_step_wall_ms` vs `ms_per_step`).
+                    "all_timed_kernel_ms_per_step": round(sum(r["ms_per_step"] for r in kernels), 3),
+                    "empty_bracket_us": round(1e3 * bracket.value, 3), "timed_launches_per_step": round(n_launch, 1),
+                    "all_timed_kernel_ms_per_step_net": round(sum(r["ms_per_step"] for r in kernels) - n_launch * bracket.value, 3),
+                    "profiled_step_wall_ms": round(prof_wall_ms, 3)}
         if dom["cfg"] == 9448:
             roofline["algorithmic_hbm_bytes_per_launch"] = 12 * B * 64 * 64 * 448
-    if world > 1:
+    if grouped:
         dist.barrier()
 
     if rank == 0:
@@ -363,6 +400,9 @@ def main():
                        "frames_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "residual_stream": "fp32"},
             "mfma_frac_whole_step": round(fps / world * gf_per_frame / (PEAK_BF16_TFLOPS * 1e12), 4),
+            "gflop_per_frame": round(gf_per_frame / 1e9, 2),
+            "process_group": ("nccl (RCCL), %d rank(s)" % world) if grouped else None,
+            "collectives_issued": collectives,
             "roofline": roofline,
             "kernels": kernels,
         }
@@ -370,7 +410,7 @@ def main():
             iters = args.cpu_iters if args.cpu_iters is not None else {1: 10, 3: 4, 4: 10}[config]
             line["cpu_baseline"] = cpu_baseline(config, 3 if config != 3 else 1, iters)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

@@ -143,6 +143,7 @@ def lib() -> C.CDLL:
         L.lsam_mlp_block_fwd_next_norm.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, vp, vp, i, i, f, vp]
         L.lsam_prof_arm.argtypes = [i]
         L.lsam_prof_read.argtypes = [i, vp, vp, vp, vp]
+        L.lsam_prof_bracket_cost.argtypes = [vp, i, vp]
         _lib = L
     return _lib
 
@@ -169,7 +170,7 @@ def dtype_code(dt: torch.dtype) -> int:
 
 
 EXPORTED = [
-    "lsam_last_error", "lsam_version", "lsam_prof_arm", "lsam_prof_read", "lsam_linear", "lsam_pack_matrix", "lsam_layernorm_fwd",
+    "lsam_last_error", "lsam_version", "lsam_prof_arm", "lsam_prof_read", "lsam_prof_bracket_cost", "lsam_linear", "lsam_pack_matrix", "lsam_layernorm_fwd",
     "lsam_layernorm_bwd", "lsam_attention_fwd", "lsam_attention_bwd", "lsam_maxpool2x2", "lsam_spatial_mean", "lsam_cast",
     "lsam_im2col_patch", "lsam_outer_reduce_ws", "lsam_outer_reduce", "lsam_hiera_create",
     "lsam_hiera_destroy", "lsam_hiera_num_blocks", "lsam_hiera_block_info", "lsam_hiera_stage_info",

@@ -260,6 +260,28 @@ int lsam_prof_read(int max, float* host_ms, double* host_flops, int* host_cfg, i
     return prof_read(max, host_ms, host_flops, host_cfg, host_mnk);
 }
 
+int lsam_prof_bracket_cost(lsam_stream_t stream, int pairs, float* host_avg_ms) {
+    LSAM_REQUIRE(host_avg_ms && pairs > 0 && pairs <= 4096, LSAM_ERR_BAD_ARG, "prof_bracket_cost: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipEvent_t e0, e1;
+    LSAM_HIP(hipEventCreate(&e0));
+    LSAM_HIP(hipEventCreate(&e1));
+    double sum = 0.0;
+    int rc = LSAM_OK;
+    for (int i = 0; i < pairs && rc == LSAM_OK; ++i) {
+        float ms = 0.f;
+        if (hipEventRecord(e0, s) != hipSuccess || hipEventRecord(e1, s) != hipSuccess ||
+            hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+            rc = LSAM_ERR_HIP;
+        sum += ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    LSAM_REQUIRE(rc == LSAM_OK, LSAM_ERR_HIP, "prof_bracket_cost: event call failed");
+    *host_avg_ms = (float)(sum / pairs);
+    return LSAM_OK;
+}
+
 size_t lsam_outer_reduce_ws(int M, int C) { return (M > 0 && C > 0) ? outer_reduce_ws(M, C) : 0; }
 
 int lsam_outer_reduce(int dtype, const void* X, int ldx, const void* Y, int ldy, int M, int C, int R, float* out,

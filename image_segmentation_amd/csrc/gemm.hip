@@ -1115,7 +1115,9 @@ __global__ __launch_bounds__(256) void skinny32_kernel(const GemmArgs p) {
         uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
         if (k0 < p.K) {
             c0 = *reinterpret_cast<const uint4*>(row + k0);
-            if constexpr (CPF == 2) c1 = *reinterpret_cast<const uint4*>(row + k0 + EPC);
+            if constexpr (CPF == 2) {   // fp32: K % 4 == 0 only, so the fragment's second chunk has a guard of its own
+                if (k0 + EPC < p.K) c1 = *reinterpret_cast<const uint4*>(row + k0 + EPC);
+            }
         }
         return make_frag(c0, c1, T{});
     };

@@ -9,7 +9,12 @@ all-reduced (RCCL, backend "nccl" on ROCm, on its own stream) as soon as that bl
 enqueued, overlapping the rest of the backward; `reduce()` then only waits, scales by 1/world and
 writes the result to `.grad`.  Without `attach` (or for gradients the hook never saw) `reduce()`
 all-reduces the buckets itself.  At this size the collective is latency-bound, not link-bound, so
-the buckets are not split further.  On CPU the same code runs over gloo (tests/test_dp_cpu.py)."""
+the buckets are not split further.  On CPU the same code runs over gloo (tests/test_dp_cpu.py).
+
+Whenever a process group exists the exchange step RUNS, whatever the group's size: a one-rank group (a 1-GPU box under
+torch.distributed.run, tests/test_dp_gpu.py) still builds the RCCL communicator, broadcasts, and all-reduces every bucket
+from inside the backward -- the mean over one rank is the identity, so results stay bit-equal to the plain step.  Only
+without any process group (plain `python bench.py`) are the calls no-ops.  `stats` counts the collectives issued."""
 from __future__ import annotations
 
 from typing import Iterable, List, Optional
@@ -54,9 +59,20 @@ class LoRAGradReducer:
         self.views = [v for b in self.buckets for v in b.views]
         self._by_first = {id(b.params[0]): b for b in self.buckets}
         self._invalidate = []   # trunks whose packed weights must be refreshed after parameters change through .data
+        self.stats = {"broadcast": 0, "all_reduce": 0, "all_reduce_from_backward": 0}
+
+    def active(self) -> bool:
+        """A process group exists: collectives are issued (also on a one-rank group)."""
+        return dist.is_available() and dist.is_initialized()
 
     def world_size(self) -> int:
-        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+        return dist.get_world_size(self.group) if self.active() else 1
+
+    def _all_reduce(self, t, from_backward=False):
+        self.stats["all_reduce"] += 1
+        if from_backward:
+            self.stats["all_reduce_from_backward"] += 1
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def attach(self, trunk) -> "LoRAGradReducer":
         """Overlap mode: the trunk's backward hands each LoRA block's gradients to on_bucket()."""
@@ -70,10 +86,11 @@ class LoRAGradReducer:
     def broadcast_params(self, src: int = 0):
         """DDP's constructor broadcast, restricted to the trainable tensors (frozen ones are built
         from the same checkpoint / seed on every rank)."""
-        if self.world_size() == 1:
+        if not self.active():
             return
         torch._foreach_copy_(self.views, [p.data for p in self.params])
         dist.broadcast(self.flat, src=src, group=self.group)
+        self.stats["broadcast"] += 1
         torch._foreach_copy_([p.data for p in self.params], self.views)
         for inv in self._invalidate:
             inv()
@@ -85,7 +102,7 @@ class LoRAGradReducer:
         b = self._by_first.get(id(params[0]))
         if b is None or len(params) != len(b.params) or any(p is not q for p, q in zip(params, b.params)):
             return   # not one of our buckets: reduce() falls back to .grad
-        if self.world_size() == 1:
+        if not self.active():
             return
         if b.filled:
             # a second backward before reduce() (gradient accumulation, two views per step): DDP sums the micro-batches.
@@ -98,23 +115,23 @@ class LoRAGradReducer:
                 views.append(inc[o:o + p.numel()].view_as(p))
                 o += p.numel()
             torch._foreach_copy_(views, list(grads))
-            b.pending.append((inc, dist.all_reduce(inc, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+            b.pending.append((inc, self._all_reduce(inc, True)))
             return
         torch._foreach_copy_(b.views, list(grads))
         b.filled = True
-        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        b.work = self._all_reduce(b.flat, True)
 
     @torch.no_grad()
     def reduce(self):
         """grads <- mean over ranks.  Missing grads count as zero (DDP semantics)."""
-        ws = self.world_size()
-        if ws == 1:
+        if not self.active():
             return
+        ws = self.world_size()
         for b in reversed(self.buckets):   # the order the backward produced (and launched) them
             if not b.filled:
                 grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b.params]
                 torch._foreach_copy_(b.views, grads)
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                b.work = self._all_reduce(b.flat)
         for b in reversed(self.buckets):
             b.work.wait()
             for inc, work in b.pending:
@@ -122,7 +139,8 @@ class LoRAGradReducer:
                 b.flat.add_(inc)
             b.pending = []
             b.work, b.filled = None, False
-        self.flat.mul_(1.0 / ws)
+        if ws > 1:
+            self.flat.mul_(1.0 / ws)
         for p, v in zip(self.params, self.views):
             if p.grad is None:
                 p.grad = v.clone()

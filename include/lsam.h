@@ -50,6 +50,11 @@ int lsam_version(void);
  * HOST arrays; returns the count.  Process-global, not thread-safe, off by default. */
 int lsam_prof_arm(int capacity);
 int lsam_prof_read(int max, float* host_ms, double* host_flops, int* host_cfg, int* host_mnk /* nullable [3*max] */);
+/* Calibration of the above (no counterpart in the reference): the average time between the two events of `pairs` EMPTY
+ * brackets on `stream` (which it synchronises).  An event pair costs the stream this much even around nothing, so a
+ * bracketed launch's duration over-states the kernel by about it; bench.py reports the sum of brackets both raw and
+ * with this subtracted per launch. */
+int lsam_prof_bracket_cost(lsam_stream_t stream, int pairs, float* host_avg_ms);
 
 /* ---- epilogue flags for lsam_linear ---- */
 enum {

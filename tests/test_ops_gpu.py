@@ -556,6 +556,28 @@ def test_linear_skinny32(dt, M, K):
     assert o32.dtype == torch.float32 and rel_err(o32.double(), ref) < (1e-6 if dt == torch.float32 else 1e-5 + 0)
 
 
+@pytest.mark.parametrize("M,N,K,few", [(1040, 32, 44, False), (2048, 32, 900, False), (37, 48, 12, True), (130, 256, 260, True),
+                                       (16, 8, 4, True)])
+def test_linear_streaming_fp32_k_not_multiple_of_8(M, N, K, few):
+    """fp32 operands need K % 4 == 0 only; an fp32 fragment is two 16-byte chunks, and for K % 8 == 4 the second chunk of the
+    last fragment lies past K.  The operand rows here are wider than K and hold NaN there (and the row after the last is NaN
+    too), so a kernel that reads past K multiplies NaNs into the result.  Both routes into the streaming kernel: N = 32
+    (the LoRA u / t products) and LSAM_EPI_FEW_ROWS."""
+    from image_segmentation_amd import ops
+    assert K % 8 == 4
+    g = torch.Generator().manual_seed(M * 7 + K)
+    abuf = torch.full((M + 1, K + 12), float("nan"))
+    wbuf = torch.full((N + 1, K + 12), float("nan"))
+    abuf[:M, :K] = torch.randn(M, K, generator=g)
+    wbuf[:N, :K] = torch.randn(N, K, generator=g) / K ** 0.5
+    abuf, wbuf = abuf.cuda(), wbuf.cuda()
+    a, w = abuf[:M], wbuf[:N]
+    ref = a[:, :K].double() @ w[:, :K].double().t()
+    out = ops.linear(a, w, K=K, few_rows=few)
+    assert torch.isfinite(out).all()
+    assert rel_err(out.double(), ref) < 2e-6
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K,epi", [(8, 256, 256, "relu"), (130, 2048, 256, "none"), (37, 8, 256, "sigmoid"), (128, 256, 2048, "res"),
                                        (5, 40, 8, "none"), (4100, 128, 264, "res")])
