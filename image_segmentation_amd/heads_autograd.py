@@ -31,18 +31,23 @@ def _as(g32: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 
 class LinearFn(torch.autograd.Function):
     """y = act(x @ W^T + b) (+ res): x T [M, K], packed W T [Npad, Kpad], fp32 bias, fp32 res [M, Npad]; returns [M, Npad]
-    (fp32 with out_f32, else T); `few_rows` = LSAM_EPI_FEW_ROWS (the token stream).  `w_param` is the module's weight when it is trainable (a LoRA factor), else None."""
+    (fp32 with out_f32, else T); `few_rows` = LSAM_EPI_FEW_ROWS (the token stream).  `w_param` / `b_param` are the module's
+    weight / bias when they are trainable, else None: a LoRA factor (rank <= 16: `lsam_outer_reduce` over the token rows),
+    or one of the dense projections `Attention_LoRA.__init__` creates fresh and leaves trainable (lora_qkv.py:26-29), whose
+    dW = g^T x and db = g^T 1 are ONE `lsam_linear` over the token rows (x extended by a column of ones)."""
 
     @staticmethod
-    def forward(ctx, x, res, w_param, pack, relu, sigmoid, out_f32, few_rows=False):
+    def forward(ctx, x, res, w_param, pack, relu, sigmoid, out_f32, few_rows=False, b_param=None):
         w, b, wT, n = pack
         y = ops.linear(x, w, b, res=res, K=x.shape[1], relu=relu, sigmoid=sigmoid, out_f32=out_f32, few_rows=few_rows)
         ctx.few_rows = few_rows
         ctx.pack, ctx.relu, ctx.sigmoid, ctx.has_res = pack, relu, sigmoid, res is not None
         ctx.x_dtype, ctx.k = x.dtype, x.shape[1]
         need_w = w_param is not None and w_param.requires_grad
-        ctx.save_for_backward(y if (relu or sigmoid) else None, x if need_w else None)
-        ctx.w_shape = tuple(w_param.shape) if need_w else None
+        ctx.need_b = b_param is not None and b_param.requires_grad
+        ctx.save_for_backward(y if (relu or sigmoid) else None, x if (need_w or ctx.need_b) else None)
+        ctx.w_shape = tuple(w_param.shape) if need_w else ((n, x.shape[1]) if ctx.need_b else None)
+        ctx.need_w = need_w
         return y
 
     @staticmethod
@@ -61,8 +66,21 @@ class LinearFn(torch.autograd.Function):
             dx = ops.linear(gT, wT, K=gT.shape[1], out_f32=ctx.x_dtype == torch.float32, few_rows=ctx.few_rows)      # dY . W, [M, Kpad]
             if dx.shape[1] != ctx.k:
                 dx = dx[:, :ctx.k].contiguous()
-        dw = None
-        if ctx.w_shape is not None and ctx.needs_input_grad[2]:
+        dw = db = None
+        if ctx.w_shape is not None and (ctx.need_b or min(ctx.w_shape) > 16):
+            # a dense trainable Linear: [dW | db] = g^T [x | 1], the M token rows being the contraction (zero-padded to 8)
+            nw, kw = ctx.w_shape
+            M = x.shape[0]
+            mp = (M + 7) // 8 * 8
+            xa = torch.zeros(M, kw + 8, dtype=torch.float32, device=x.device)      # placement only
+            xa[:, :kw] = _f32(x)[:, :kw]
+            xa[:, kw] = 1.0
+            gt = ops.pack_matrix(g32[:, :nw].t(), w.dtype, ld=mp)                  # [nw, mp]
+            xt = ops.pack_matrix(xa.t(), w.dtype, ld=mp)                           # [kw + 8, mp]
+            o = ops.linear(gt, xt, out_f32=True)                                   # [nw, kw + 8]
+            dw = o[:, :kw].contiguous() if ctx.need_w else None
+            db = o[:, kw].contiguous() if ctx.need_b else None
+        elif ctx.w_shape is not None and ctx.needs_input_grad[2]:
             nw, kw = ctx.w_shape
             # dW[n][k] = sum_m g[m][n] x[m][k]: the reduction runs over the side with <= 16 columns (the LoRA rank)
             if nw <= 16:
@@ -73,9 +91,7 @@ class LinearFn(torch.autograd.Function):
                 x16 = torch.zeros(x.shape[0], 16, dtype=x.dtype, device=x.device)
                 x16[:, :min(16, x.shape[1])] = x[:, :16]
                 dw = ops.outer_reduce(gT[:, :nw].contiguous(), x16, kw, transpose_out=False)     # [nw, kw]
-            else:
-                raise RuntimeError("LinearFn: weight gradients exist for rank <= 16 LoRA factors only")
-        return dx, d_res, dw, None, None, None, None, None
+        return dx, d_res, dw, None, None, None, None, None, db
 
 
 class LayerNormFn(torch.autograd.Function):

@@ -27,7 +27,9 @@ from ._C import check, lib, ptr, stream
 
 
 class PatchEmbed(nn.Module):
-    """backbones/utils.py:63-93.  Holds the 7x7/s4/p3 conv weights; computed by im2col + GEMM."""
+    """backbones/utils.py:63-93.  Holds the 7x7/s4/p3 conv weights.  Inside `Hiera.forward` the convolution is the direct
+    MFMA kernel of csrc/patchembed.hip (bias and position embedding fused); this stand-alone `forward` is the unit-operator
+    form (lsam_im2col_patch + lsam_linear), kept for callers that invoke the module on its own."""
 
     def __init__(self, kernel_size=(7, 7), stride=(4, 4), padding=(3, 3), in_chans: int = 3,
                  embed_dim: int = 768):
@@ -56,6 +58,35 @@ class MLP(nn.Module):
         self.sigmoid_output = sigmoid_output
         self.act = activation()
 
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """sam2_utils.py:131-136 as unit operators (inference): one `lsam_linear` per layer with the activation (exact-erf
+        GELU in Hiera, ReLU in the SAM heads) and the optional final sigmoid in its epilogue; fp32 out.  Inside `Hiera.forward`
+        / `SAM2Base._forward_sam_heads` the same layers run fused or through autograd nodes instead."""
+        if not isinstance(self.act, (nn.GELU, nn.ReLU)):
+            raise _C.LsamError(f"MLP.forward: activation {type(self.act).__name__} is not built (GELU and ReLU are)")
+        dt = _compute_dtype(None)
+        lead = x.shape[:-1]
+        h = x.reshape(-1, x.shape[-1])
+        h = h.to(dt).contiguous() if h.dtype != dt else h.contiguous()
+        for i, layer in enumerate(self.layers):
+            last = i == self.num_layers - 1
+            n, k = layer.weight.shape
+            n8, k8 = (n + 7) // 8 * 8, (k + 7) // 8 * 8
+            wp = torch.zeros(n8, k8, dtype=torch.float32, device=h.device)       # placement only: pad to the GEMM's granule
+            wp[:n, :k] = layer.weight.detach().float()
+            bp = torch.zeros(n8, dtype=torch.float32, device=h.device)
+            bp[:n] = layer.bias.detach().float()
+            if h.shape[1] != k8:
+                hp = torch.zeros(h.shape[0], k8, dtype=h.dtype, device=h.device)
+                hp[:, :k] = h[:, :k]
+                h = hp
+            h = ops.linear(h, ops.pack_matrix(wp, dt), bp, gelu=not last and isinstance(self.act, nn.GELU),
+                           relu=not last and isinstance(self.act, nn.ReLU), sigmoid=last and self.sigmoid_output, out_f32=last)
+            if last:
+                h = h[:, :n]
+        return h.reshape(*lead, h.shape[-1])
+
 
 def _compute_dtype(explicit: Optional[torch.dtype]) -> torch.dtype:
     if explicit is not None:
@@ -66,7 +97,7 @@ def _compute_dtype(explicit: Optional[torch.dtype]) -> torch.dtype:
 
 
 class MultiScaleAttention(nn.Module):
-    """hieradet.py:39-81.  Parameter container; see MultiScaleBlock.forward."""
+    """hieradet.py:39-81."""
 
     def __init__(self, dim: int, dim_out: int, num_heads: int, q_pool: nn.Module = None):
         super().__init__()
@@ -76,6 +107,29 @@ class MultiScaleAttention(nn.Module):
         self.q_pool = q_pool
         self.qkv = nn.Linear(dim, dim_out * 3)
         self.proj = nn.Linear(dim_out, dim_out)
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """hieradet.py:56-81 as unit operators (inference): x [B, H, W, dim] -> [B, H', W', dim_out]; every one of the B maps is
+        ONE attention window of H x W tokens (the reference calls this on window-partitioned input), q max-pooled 2 x 2 when
+        the block has a q_pool.  `MultiScaleBlock.forward` / `Hiera.forward` do not come through here (they address windows in
+        place); geometries the attention kernels do not cover raise LsamError."""
+        from .lora_qkv import LoRA_qkv
+        dt = _compute_dtype(None)
+        B, H, W, d = x.shape
+        q = self.dim_out
+        xt = x.reshape(-1, d)
+        xt = xt.to(dt).contiguous() if xt.dtype != dt else xt.contiguous()
+        if isinstance(self.qkv, LoRA_qkv):
+            qkv, bias = self.qkv._forward_packed(xt), self.qkv.qkv.bias
+        else:
+            qkv, bias = ops.linear(xt, ops.pack_matrix(self.qkv.weight.detach().float(), dt), self.qkv.bias), self.qkv.bias
+        pool = 2 if self.q_pool is not None else 1
+        ws = H if H == W else 0            # one H x H window per map; a non-square map takes the global form (window 0)
+        a = ops.attention_fwd(qkv.view(B, H, W, 3 * q), bias, ws, pool, self.num_heads)
+        Ho, Wo = a.shape[1:3]
+        out = ops.linear(a.view(-1, q), ops.pack_matrix(self.proj.weight.detach().float(), dt), self.proj.bias, out_f32=True)
+        return out.view(B, Ho, Wo, q)
 
 
 class MultiScaleBlock(nn.Module):

@@ -6,8 +6,9 @@ The work over the pixels -- the only part with any size: [N, M, H, W] logits at 
 prediction step (`lsam_mask_loss_sums`: per candidate mask the focal sum, sum p t, sum p, sum t and the two areas) and one
 elementwise pass in the backward (`lsam_mask_loss_bwd`); what is left is arithmetic on [N, M] tensors (ratios, the
 arg-min over the candidates, the weighted sum), which torch does on the device, autograd included.
-Binary {0, 1} targets are assumed, as every caller of the reference provides them (the reference's `targets.sigmoid()`
-branch for targets outside [0, 1], loss_fns.py:35-36, is not built and raises)."""
+Binary {0, 1} targets are ASSUMED, as every caller of the reference provides them, and NOT checked (a check would be one
+more pass over the targets, or a host synchronisation as in the reference): the reference's `targets.sigmoid()` branch for
+targets outside [0, 1] (loss_fns.py:35-36) is not built, so results for such targets are undefined here."""
 from __future__ import annotations
 
 from collections import defaultdict
@@ -35,9 +36,19 @@ def _sums(inputs: torch.Tensor, targets: torch.Tensor, alpha: float, gamma: floa
 
 
 def dice_loss(inputs, targets, num_objects, loss_on_multimask=False):
-    """loss_fns.py:19-55."""
-    x = inputs if inputs.dim() == 4 else inputs.unsqueeze(1)
-    s = _sums(x, targets if inputs.dim() == 4 else targets.unsqueeze(1), -1.0, 0.0)
+    """loss_fns.py:19-55.  `loss_on_multimask`: [N, M, H, W] inputs and targets, one dice per (n, m).  Otherwise the reference
+    flattens the inputs to [N, K] and multiplies by the targets AS GIVEN (loss_fns.py:47-48), which only works for targets
+    that are already [N, K]: that form is reproduced, one dice per n; other shapes fail in the reference and raise here."""
+    if loss_on_multimask:
+        if inputs.dim() != 4 or targets.dim() != 4:
+            raise LsamError("dice_loss(loss_on_multimask=True) takes [N, M, H, W] inputs and targets (loss_fns.py:41)")
+        x, t = inputs, targets
+    else:
+        if targets.dim() != 2 or inputs.shape[0] != targets.shape[0] or inputs[0].numel() != targets.shape[1]:
+            raise LsamError("dice_loss(loss_on_multimask=False): the reference's form needs targets of shape [N, K] matching the "
+                            "flattened inputs (loss_fns.py:47-48); other shapes fail there too")
+        x, t = inputs.reshape(inputs.shape[0], 1, -1), targets.unsqueeze(1)
+    s = _sums(x, t, -1.0, 0.0)
     loss = 1 - (2 * s[..., 1] + 1) / (s[..., 2] + s[..., 3] + 1)
     return loss / num_objects if loss_on_multimask else loss.sum() / num_objects
 

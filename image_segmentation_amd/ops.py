@@ -572,6 +572,18 @@ def mha_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor
     dout = _f32c(dout)
     B, nq, Cc = q.shape
     nk = k.shape[1]
+    if nq > 16 and nk > 16:
+        # the kernels keep one side (<= 16 rows) in LDS.  Attention rows are independent, so more than 16 tokens on BOTH sides
+        # (the two-way transformer's self-attention with more than 9 accumulated clicks) is exact as a sum over query groups
+        # of 16: each group gives its own dq rows and a dk / dv contribution.
+        dq = torch.empty(B, nq, Cc, dtype=torch.float32, device=q.device)
+        dk = dv = None
+        for o in range(0, nq, 16):
+            e = min(nq, o + 16)
+            dqc, dkc, dvc = mha_bwd(q[:, o:e], k, v, out[:, o:e], dout[:, o:e], nh)
+            dq[:, o:e] = dqc
+            dk, dv = (dkc, dvc) if dk is None else (dk.add_(dkc), dv.add_(dvc))
+        return dq, dk, dv
     dq = torch.empty(B, nq, Cc, dtype=torch.float32, device=q.device)
     dk = torch.empty(B, nk, Cc, dtype=torch.float32, device=q.device)
     dv = torch.empty(B, nk, Cc, dtype=torch.float32, device=q.device)

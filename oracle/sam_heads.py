@@ -134,6 +134,40 @@ def make_head_params(seed: int = 0) -> Params:
     return {n: synth_head_tensor(n, s, seed) for n, s in head_param_shapes()}
 
 
+def decoder_lora_params(rank: int = 4, seed: int = 0) -> Params:
+    """What the reference's `wrap_decoder_lora` (lora_qkv.py:112-143) ADDS to the mask decoder, with seeded values: per
+    transformer layer the four factors A_q [r, D], B_q [D, r], A_v [r, D], B_v [D, r] (non-zero B, so that every gradient
+    is non-trivial) and the FRESH q / k / v / out projections `Attention_LoRA.__init__` creates in place of the wrapped
+    ones (lora_qkv.py:26-29); the latter take the place of the `self_attn.*_proj.*` entries of make_head_params."""
+    out: Params = {}
+    for l in range(2):
+        pre = f"sam_mask_decoder.transformer.layers.{l}.self_attn."
+        for n, shape in (("A_q.weight", (rank, D)), ("B_q.weight", (D, rank)), ("A_v.weight", (rank, D)), ("B_v.weight", (D, rank))):
+            g = _gen("decoder_lora." + pre + n, seed)
+            out[pre + n] = torch.randn(shape, generator=g) * (1.0 / math.sqrt(D) if n[0] == "A" else 0.05)
+        for proj in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            for leaf, shape in (("weight", (D, D)), ("bias", (D,))):
+                out[pre + f"{proj}.{leaf}"] = synth_head_tensor("fresh." + pre + f"{proj}.{leaf}", shape, seed)
+    return out
+
+
+def functional_weights(B: int, seed: int = 4242):
+    """Fixed random weights (wl, wi, wo) of the scalar functional the decoder-LoRA gradient goldens differentiate:
+    L = sum(low_res_multimasks * wl) + sum(ious * wi) + sum(object_score_logits * wo)."""
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(B, 3, 256, 256, generator=g) / 256.0, torch.randn(B, 3, generator=g), torch.randn(B, 1, generator=g))
+
+
+def synthetic_fpn(B: int, seed: int = 3):
+    """Encoder-like pyramid: std ~5 smooth-ish features (the regime synth_head_tensor's scales were chosen for)."""
+    g = torch.Generator().manual_seed(seed)
+    f2 = 5 * torch.randn(B, 256, 64, 64, generator=g)
+    f2 = F.avg_pool2d(F.pad(f2, (2, 2, 2, 2), mode="replicate"), 5, 1) * 2.5       # spatially correlated
+    f1 = F.interpolate(f2, scale_factor=2, mode="nearest") + torch.randn(B, 256, 128, 128, generator=g)
+    f0 = F.interpolate(f1, scale_factor=2, mode="nearest") + torch.randn(B, 256, 256, 256, generator=g)
+    return f0, f1, f2
+
+
 # ---------------------------------------------------------------------------------------------
 # prompt encoder  (sam/prompt_encoder.py, position_encoding.py:133-176)
 # ---------------------------------------------------------------------------------------------
@@ -181,9 +215,15 @@ def _mlp(hp: Params, pre: str, x: torch.Tensor, n: int, sigmoid: bool = False) -
 
 
 def _attention(hp: Params, pre: str, q, k, v, nh: int = 8) -> torch.Tensor:
+    """sam/transformer.py:233-265; with `A_q / B_q / A_v / B_v` entries under `pre` it is Attention_LoRA.forward
+    (lora_qkv.py:49-67): q = q_proj(q) + B_q(A_q(q)), v = v_proj(v) + B_v(A_v(v)), no scaling, no bias on the factors."""
+    q_in, v_in = q, v
     q = F.linear(q, hp[pre + "q_proj.weight"], hp[pre + "q_proj.bias"])
     k = F.linear(k, hp[pre + "k_proj.weight"], hp[pre + "k_proj.bias"])
     v = F.linear(v, hp[pre + "v_proj.weight"], hp[pre + "v_proj.bias"])
+    if pre + "A_q.weight" in hp:
+        q = q + F.linear(F.linear(q_in, hp[pre + "A_q.weight"]), hp[pre + "B_q.weight"])
+        v = v + F.linear(F.linear(v_in, hp[pre + "A_v.weight"]), hp[pre + "B_v.weight"])
 
     def heads(x):
         b, n, c = x.shape

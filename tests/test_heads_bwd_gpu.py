@@ -103,7 +103,7 @@ def _heads_with_lora(seed, dtype, rank=4):
     from image_segmentation_amd.sam_heads import wrap_decoder_lora
     from test_heads_gpu import _make_heads
     m, hp = _make_heads(seed, dtype)
-    wrap_decoder_lora(m, rank)                    # freezes the decoder, adds the factors
+    wrap_decoder_lora(m, rank, fresh_projections=False)                    # freezes the decoder, adds the factors
     for p in m.parameters():
         p.requires_grad = False
     gen = torch.Generator().manual_seed(21)

@@ -120,13 +120,8 @@ def _make_heads(seed=0, dtype=torch.float32):
 
 
 def _synthetic_fpn(B, seed=3):
-    """Encoder-like pyramid: std ~5 smooth-ish features (the regime oracle.synth_head_tensor's scales were chosen for)."""
-    g = torch.Generator().manual_seed(seed)
-    f2 = 5 * torch.randn(B, 256, 64, 64, generator=g)
-    f2 = F.avg_pool2d(F.pad(f2, (2, 2, 2, 2), mode="replicate"), 5, 1) * 2.5       # spatially correlated
-    f1 = F.interpolate(f2, scale_factor=2, mode="nearest") + torch.randn(B, 256, 128, 128, generator=g)
-    f0 = F.interpolate(f1, scale_factor=2, mode="nearest") + torch.randn(B, 256, 256, 256, generator=g)
-    return f0, f1, f2
+    from oracle import sam_heads as SH
+    return SH.synthetic_fpn(B, seed)
 
 
 def _run_product(m, hp, fpn, coords, labels):
@@ -220,7 +215,7 @@ def test_decoder_lora(dtype):
     fpn = _synthetic_fpn(B, seed=7)
     coords, labels = torch.tensor([[[600.0, 333.0]]]), torch.ones(B, 1, dtype=torch.int32)
     base = _run_product(m, hp, fpn, coords, labels)
-    wrap_decoder_lora(m, 4)
+    wrap_decoder_lora(m, 4, fresh_projections=False)
     layers = m.sam_mask_decoder.transformer.layers
     assert all(isinstance(b.self_attn, Attention_LoRA) for b in layers)
     assert not any(p.requires_grad for n, p in m.sam_mask_decoder.named_parameters() if ".A_" not in n and ".B_" not in n)
@@ -274,12 +269,12 @@ def test_decoder_lora_training_steps_refresh_packed_weights():
 
     def fresh_copy(src):
         m2, hp2 = _make_heads(4)
-        wrap_decoder_lora(m2, 4)
+        wrap_decoder_lora(m2, 4, fresh_projections=False)
         m2.load_state_dict(src.state_dict(), strict=True)
         return m2, hp2
 
     m, hp = _make_heads(4)
-    wrap_decoder_lora(m, 4)
+    wrap_decoder_lora(m, 4, fresh_projections=False)
     for n, p in m.named_parameters():          # train_lora_sam.py:116-117 freezes everything but the LoRA factors
         p.requires_grad = ".A_" in n or ".B_" in n
     lora = [p for p in m.parameters() if p.requires_grad]
@@ -302,7 +297,7 @@ def test_decoder_lora_training_steps_refresh_packed_weights():
     assert torch.equal(after, _run_product(m2, hp2, fpn, coords, labels)["low_res_multimasks"].detach())
     # load_state_dict into a model that has already packed: the old images must not survive
     m3, hp3 = _make_heads(4)
-    wrap_decoder_lora(m3, 4)
+    wrap_decoder_lora(m3, 4, fresh_projections=False)
     _run_product(m3, hp3, fpn, coords, labels)
     m3.load_state_dict(m.state_dict(), strict=True)
     assert torch.equal(after, _run_product(m3, hp3, fpn, coords, labels)["low_res_multimasks"].detach())

@@ -49,7 +49,7 @@ def test_whole_training_step_vs_restatements():
     for name, p in model.named_parameters():
         if not name.startswith("image_encoder."):
             p.requires_grad = False
-    wrap_decoder_lora(model, 4)
+    wrap_decoder_lora(model, 4, fresh_projections=False)
     gen = torch.Generator().manual_seed(5)
     dec_lora = []
     for blk in model.sam_mask_decoder.transformer.layers:
