@@ -118,10 +118,26 @@ def build(device, cfg=BPLUS, lora_rank=4):
     return enc
 
 
+class _MeanSquare(torch.autograd.Function):
+    """mean(f^2) with fp32 accumulation as ONE reduction over f (||f||_2^2 / numel: no fp32 copy or square of the level is
+    materialised) and ONE elementwise kernel in the backward (f * (2 g / numel), the scale an fp32 scalar, the product
+    rounded once to f's dtype) -- torch's own graph for the same expression differentiates pow and norm separately, two
+    passes over the level."""
+
+    @staticmethod
+    def forward(ctx, f):
+        ctx.save_for_backward(f)
+        return torch.linalg.vector_norm(f, dtype=torch.float32) ** 2 / f.numel()
+
+    @staticmethod
+    def backward(ctx, g):
+        (f,) = ctx.saved_tensors
+        return f * (g.float() * (2.0 / f.numel()))
+
+
 def fpn_loss(out):
-    """sum_l mean(fpn_l^2), evaluated as ||f||_2^2 / numel with fp32 accumulation: one read of
-    each level instead of materialising fp32 copies and squares of the 256x256x256 level."""
-    return sum(torch.linalg.vector_norm(f, dtype=torch.float32) ** 2 / f.numel() for f in out["backbone_fpn"])
+    """sum_l mean(fpn_l^2): the synthetic loss of SURVEY.md section 8d."""
+    return sum(_MeanSquare.apply(f) for f in out["backbone_fpn"])
 
 
 def cpu_baseline(config: int, warm: int, iters: int):
@@ -258,7 +274,7 @@ def main():
                     p_.requires_grad = False                   # train_lora_sam.py:116-117 freezes everything but LoRA
         reducer = LoRAGradReducer(lora).attach(enc.trunk)   # per-block buckets, all-reduce overlapped with backward
         reducer.broadcast_params(0)
-        opt = torch.optim.AdamW(lora, lr=1e-4)   # config.yaml:6 of the reference
+        opt = torch.optim.AdamW(lora, lr=1e-4, fused=True)   # config.yaml:6 of the reference; fused: the same update as ONE kernel
         img = synth_frames_device(B, 1024, 0, device, first_index=rank * B)   # resident before timing
         steps = args.steps if args.steps is not None else 20
         frames_per_step = B

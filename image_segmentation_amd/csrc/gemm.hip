@@ -828,7 +828,9 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
 #pragma unroll
         for (int mp = 0; mp < 2; ++mp) {
             const int py = (py0 >> 1) + wm / pWX, px = (px0 + 32 * (wm % pWX) + 16 * mp + lr) >> 1;
-            float* rowp = static_cast<float*>(p.out) + (((size_t)pn * hh + py) * hw + px) * p.ldo + nc;
+            const bool second = p.split_n > 0 && n0 >= p.split_n;   // workgroup-uniform: a column tile belongs to one output
+            float* rowp = second ? static_cast<float*>(p.out2) + (((size_t)pn * hh + py) * hw + px) * p.ldo2 + (nc - p.split_n)
+                                 : static_cast<float*>(p.out) + (((size_t)pn * hh + py) * hw + px) * p.ldo + nc;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 f32x4 v;
@@ -1198,7 +1200,8 @@ template <typename T> int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
                  "linear: need N%%8==0 and K%%%d==0 (N=%d K=%d)", EPC, a.N, a.K);
     LSAM_REQUIRE(a.lda % EPC == 0 && a.ldw % EPC == 0 && aligned16(a.A) && aligned16(a.W),
                  LSAM_ERR_BAD_ARG, "linear: operand rows must be 16-byte aligned");
-    LSAM_REQUIRE(a.lda >= a.K && a.ldw >= a.K && a.ldo >= a.N, LSAM_ERR_BAD_ARG, "linear: bad leading dimension");
+    LSAM_REQUIRE(a.lda >= a.K && a.ldw >= a.K && a.ldo >= (a.split_n > 0 ? a.split_n : a.N), LSAM_ERR_BAD_ARG, "linear: bad leading dimension");
+    LSAM_REQUIRE(a.split_n == 0 || a.pool_w > 0, LSAM_ERR_BAD_ARG, "linear: split_n goes with the pooled epilogue only");
     LSAM_REQUIRE(a.ldo % 4 == 0 && aligned16(a.out) && (!a.bias || aligned16(a.bias)), LSAM_ERR_BAD_ARG,
                  "linear: out/bias alignment");
     LSAM_REQUIRE(!a.res || (a.ldres % 4 == 0 && aligned16(a.res)), LSAM_ERR_BAD_ARG, "linear: res alignment");
@@ -1242,6 +1245,9 @@ template <typename T> int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     }
     if (a.pool_w > 0) {
         if constexpr (sizeof(T) == 2) {
+            LSAM_REQUIRE(a.split_n == 0 || (GEMM3 && a.split_n % 224 == 0 && a.split_n < a.N && a.out2 && a.ldo2 % 4 == 0 &&
+                                            a.ldo2 >= a.N - a.split_n && a.ldo >= a.split_n && aligned16(a.out2)),
+                         LSAM_ERR_BAD_ARG, "linear: bad split of the pooled output");
             LSAM_REQUIRE(gemm_pool_supported(a.pool_h, a.pool_w, a.N) && a.M % (a.pool_h * a.pool_w) == 0 &&
                              (a.flags & ~LSAM_EPI_OUT_F32) == 0 && (a.flags & LSAM_EPI_OUT_F32) && !a.res &&
                              (double)a.M * a.lda * sizeof(T) < 2.0e9 && (double)a.N * a.ldw * sizeof(T) < 2.0e9,

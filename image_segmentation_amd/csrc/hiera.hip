@@ -24,6 +24,9 @@ namespace lsam {
 
 constexpr int AUG = 32;       // extra K columns: [q part 16 | v part 16]
 constexpr int PATCH_K = 160;  // 3*7*7 = 147 padded to a multiple of 16
+#ifndef MERGE_POOLED
+#define MERGE_POOLED 1        // a stage-entry block's shortcut and pooled queries from ONE pooled GEMM (0: two launches)
+#endif
 
 struct BlockGeom {
     int dim, dout, heads, ws, pool, gin, gout, stage;
@@ -220,6 +223,10 @@ static int pack_t(lsam_hiera* h, const lsam_block_params_t* bp, const float* pat
         if (d != q) {
             LSAM_TRY(launch_pack_matrix<T>(p.proj_w, d, 1, q, d, at<T>(arena, o.wsc), d, s));
             LSAM_TRY(vec(p.proj_b, o.bsc, q));
+            if (!g.lora) {   // [W_proj ; W_q] and [b_proj ; b_q]: one pooled GEMM gives the shortcut and the pooled queries
+                LSAM_TRY(launch_pack_matrix<T>(p.qkv_w, d, 1, q, d, at<T>(arena, o.wsc) + (size_t)q * d, d, s));
+                LSAM_TRY(vec(p.qkv_b, o.bsc + (size_t)q * 4, q));
+            }
         }
         if (g.fused_attn)
             LSAM_TRY(launch_pack_winblock(p.qkv_w, p.qkv_b, p.attn_proj_w, p.attn_proj_b, g.heads, q / g.heads,
@@ -315,14 +322,26 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
         else if (d != q) y = stage_out[g.stage];
         else y = x;
         const float* res = x;
+        // q-pool blocks: the q third of the projection goes through the GEMM's pooling epilogue (only the pooled
+        // queries, a quarter of the rows, ever exist: do_pool(q), hieradet.py:69-71) and only k | v are written at
+        // full resolution.  The pooled shortcut leaves its un-pooled scratch free for them.
+        const bool qpooled = g.pool == 2 && d != q && sizeof(T) == 2 && !g.lora && !grad && (q / g.heads) % 8 == 0 &&
+                             gemm_pool_supported(g.gin, g.gin, q) && (2 * q) % 224 == 0 && Mi >= 1024;
+        float* qp = qpooled ? at<float>(ws, w.scpre) : nullptr;
+        bool q_done = false;
         if (d != q) {  // shortcut = pool(proj(norm1(x)))  (hieradet.py:139-140)
             if (g.pool == 2 && sizeof(T) == 2 && gemm_pool_supported(g.gin, g.gin, q)) {
-                // the 2x2 max-pool is taken in the GEMM's epilogue: the full-resolution fp32 product never exists
+                // the 2x2 max-pool is taken in the GEMM's epilogue: the full-resolution fp32 product never exists.  With
+                // pooled queries the same launch produces them too (N = 2 q over [W_proj ; W_q], columns >= q to qp): both
+                // are pooled products of the same LN1 rows, which are then read once
+                const bool both = qpooled && MERGE_POOLED && g.kq == d && q % 224 == 0;
                 GemmArgs ga{xn, g.kq, at<T>(arena, o.wsc), d, at<float>(arena, o.bsc), nullptr, 0, 0, nullptr, 0, y, q,
-                            nullptr, 0, LSAM_EPI_OUT_F32, Mi, q, d};
+                            both ? static_cast<void*>(qp) : nullptr, both ? q : 0, LSAM_EPI_OUT_F32, Mi, both ? 2 * q : q, d};
                 ga.pool_h = g.gin;
                 ga.pool_w = g.gin;
+                ga.split_n = both ? q : 0;
                 LSAM_TRY(launch_gemm<T>(ga, s));
+                q_done = both;
             } else {
                 float* sc = g.pool == 2 ? at<float>(ws, w.scpre) : y;
                 LSAM_TRY(linear<T>(xn, g.kq, at<T>(arena, o.wsc), d, at<float>(arena, o.bsc), nullptr, 0, 0, nullptr, 0, sc,
@@ -333,19 +352,14 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
         }
         // ---- qkv (+LoRA through the augmented K columns) ------------------------------------------
         T* qkv = grad ? at<T>(ws, w.sv[gi].qkv) : at<T>(ws, w.qkv);
-        // q-pool blocks: the q third of the projection goes through the GEMM's pooling epilogue (only the pooled
-        // queries, a quarter of the rows, ever exist: do_pool(q), hieradet.py:69-71) and only k | v are written at
-        // full resolution.  The pooled shortcut above leaves its un-pooled scratch free for them.
-        const bool qpooled = g.pool == 2 && d != q && sizeof(T) == 2 && !g.lora && !grad && (q / g.heads) % 8 == 0 &&
-                             gemm_pool_supported(g.gin, g.gin, q) && (2 * q) % 224 == 0 && Mi >= 1024;
-        float* qp = nullptr;
         if (qpooled) {
-            qp = at<float>(ws, w.scpre);
-            GemmArgs gq{xn, g.kq, at<T>(arena, o.wqkv), g.kq, at<float>(arena, o.bqkv), nullptr, 0, 0, nullptr, 0, qp, q,
-                        nullptr, 0, LSAM_EPI_OUT_F32, Mi, q, g.kq};
-            gq.pool_h = g.gin;
-            gq.pool_w = g.gin;
-            LSAM_TRY(launch_gemm<T>(gq, s));
+            if (!q_done) {
+                GemmArgs gq{xn, g.kq, at<T>(arena, o.wqkv), g.kq, at<float>(arena, o.bqkv), nullptr, 0, 0, nullptr, 0, qp, q,
+                            nullptr, 0, LSAM_EPI_OUT_F32, Mi, q, g.kq};
+                gq.pool_h = g.gin;
+                gq.pool_w = g.gin;
+                LSAM_TRY(launch_gemm<T>(gq, s));
+            }
             if (!g.fused_kv)
                 LSAM_TRY(linear<T>(xn, g.kq, at<T>(arena, o.wqkv) + (size_t)q * g.kq, g.kq, at<float>(arena, o.bqkv) + q, nullptr, 0,
                                    0, nullptr, 0, qkv + q, 3 * q, nullptr, 0, 0, Mi, 2 * q, g.kq, s));
@@ -613,9 +627,9 @@ int lsam_hiera_create(const lsam_hiera_config_t* c, lsam_hiera_t** out) {
         o.b1 = b.take(4 * q * 4);
         o.w2 = b.take(4 * q * q * e);
         o.b2 = b.take(q * 4);
-        if (d != q) {
-            o.wsc = b.take(q * d * e);
-            o.bsc = b.take(q * 4);
+        if (d != q) {   // non-LoRA blocks: the q rows of the qkv projection follow the shortcut projection's (see pack_t)
+            o.wsc = b.take((g.lora ? 1 : 2) * q * d * e);
+            o.bsc = b.take((g.lora ? 1 : 2) * q * 4);
         }
         if (g.fused_attn) {
             o.wimg = b.take(winblock_image_bytes(g.heads));

@@ -17,6 +17,10 @@ struct GemmArgs {
     // optional 2x2 max-pool of the OUTPUT rows (rows = tokens of an [pool_n][pool_h][pool_w] grid, M = their
     // product): out then has M / 4 rows.  bf16 operands, fp32 out, N % 224 == 0, bias only (see gemm_pool_supported).
     int pool_h = 0, pool_w = 0;
+    // pooled epilogue only: output columns >= split_n go to out2 (fp32, leading dimension ldo2) at column - split_n, so ONE
+    // pooled GEMM over concatenated weights serves two consumers (a stage-entry block's shortcut and its pooled queries,
+    // hieradet.py:139-140 and :64-67, both products of the same LN1 rows).  split_n % 224 == 0.
+    int split_n = 0;
 };
 bool gemm_pool_supported(int H, int W, int N);
 template <typename T> int launch_gemm(const GemmArgs& a, hipStream_t s);
