@@ -225,6 +225,26 @@ def test_attention_fwd(ops, dt, H, ws, pool, nh):
     assert rel_err(lse, lse_ref) < tol(dt, 1e-5, 2e-3)
 
 
+@pytest.mark.parametrize("N,H,W,nh,hd", [(1, 16, 16, 2, 56), (2, 64, 64, 2, 56), (3, 64, 64, 8, 56), (2, 40, 64, 4, 56), (5, 30, 18, 8, 56),
+                                         (2, 28, 28, 3, 64), (2, 42, 42, 16, 32), (1, 64, 64, 8, 56)])
+def test_attention_fwd_window14_inference_form(ops, N, H, W, nh, hd):
+    """The inference form (no log-sum-exp) of the 14 x 14 windows in bf16: more (window, head) items than the chip has
+    workgroup slots, fewer, one; windows cut by the right / bottom edge (pad-token keys = bias), non-square grids, head_dim 64
+    (no free padding channel for the softmax denominator) and 32.  Against the fp32 reference, and bit for bit against the
+    form that also returns the log-sum-exp (the LoRA blocks' forward)."""
+    ws, dt = 14, torch.bfloat16
+    qkv = rnd(N, H, W, 3 * nh * hd, seed=N + H + W).cuda().to(dt)
+    bias = rnd(3 * nh * hd, seed=9) * 0.5
+    out = ops.attention_fwd(qkv, bias.cuda(), ws, 1, nh)
+    ref, _ = ref_attention(qkv.float().cpu(), bias.cuda().to(dt).float().cpu(), H, W, ws, 1, nh)
+    assert out.shape == ref.shape
+    assert rel_err(out.float(), ref) < 6e-3
+    old, _ = ops.attention_fwd(qkv, bias.cuda(), ws, 1, nh, want_lse=True)
+    assert torch.equal(out, old)
+    again = ops.attention_fwd(qkv, bias.cuda(), ws, 1, nh)
+    assert torch.equal(out, again)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("hd", [72, 96])
 @pytest.mark.parametrize("H,ws,pool,nh", [(16, 8, 1, 2), (16, 8, 2, 2), (32, 16, 1, 4), (32, 16, 2, 2), (16, 0, 1, 2), (64, 0, 1, 1),
