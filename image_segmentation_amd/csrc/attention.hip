@@ -386,7 +386,7 @@ __device__ uint4 g_attn_one16 = {0x00003F80u, 0u, 0u, 0u};   // bf16 1.0 followe
 // KSQ = 32-wide k-steps of Q K^T, DT = 16-wide output tiles: (2, 4) for head_dim <= 64 (128-byte tile rows);
 // (3, 5) / (3, 6) for head_dim <= 80 / 96 (Hiera-L: 72, Hiera-T/S: 96) on 256-byte tile rows of 16 chunks.
 template <int QT, bool ONES, int KSQ = 2, int DT = 4>
-__global__ __launch_bounds__(256, (QT == 2 && KSQ == 2) ? 3 : 2) void attn2_fwd_kernel(const AttnArgs p, const float c_log2) {
+__global__ __launch_bounds__(256, (QT == 2 && KSQ == 2) ? 3 : 2) void attn2_fwd_kernel(const AttnArgs p, const float c_log2, const int nqb) {
     using T = bf16;
     static_assert((KSQ == 2 && DT == 4) || (KSQ == 3 && (DT == 5 || DT == 6)), "supported head_dim classes");
     constexpr int KT2 = 64, RB = KSQ == 2 ? 128 : 256, TILE_B = KT2 * RB, STAGE = 2 * TILE_B;
@@ -400,12 +400,20 @@ __global__ __launch_bounds__(256, (QT == 2 && KSQ == 2) ? 3 : 2) void attn2_fwd_
     const int g = lane >> 4, lr = lane & 15;
     const int H = p.H, W = p.W, nh = p.nh, hd = p.hd, dout = nh * hd;
     const WinGeom G = make_geom(H, W, p.ws, p.pool);
-    const int h = blockIdx.y;
-    const int win = blockIdx.x % (G.nwy * G.nwx), n = blockIdx.x / (G.nwy * G.nwx);
+    // 1-D grid, XCD-aware (workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2): XCD x takes the
+    // windows w = x (mod 8); within it the query blocks of one (window, head) are consecutive and the heads of a window
+    // follow each other.  The workgroups an XCD runs at one time then stream the K / V of two or three (window, head)
+    // pairs (0.9 MB each for a 4096-key global block) out of its L2, instead of all heads of two frames (15 MB): the old
+    // (window, head, query block) grid order fetched 965 MB per launch for 176 MB of q / k / v.  The heads of a window
+    // share the 128-byte lines their 112-byte slices straddle, so they stay on one XCD.
+    const int nwin_all = p.N * G.nwy * G.nwx;
+    const int j_ = blockIdx.x >> 3, z_ = j_ % nqb, h = (j_ / nqb) % nh, gwin = (j_ / (nqb * nh)) * 8 + (blockIdx.x & 7);
+    if (gwin >= nwin_all) return;   // uniform for the workgroup, before any barrier
+    const int win = gwin % (G.nwy * G.nwx), n = gwin / (G.nwy * G.nwx);
     const int wy = win / G.nwx, wx = win % G.nwx;
     const int rh = min(G.qh, G.Ho - wy * G.qh), rw = min(G.qw, G.Wo - wx * G.qw);
     const int nq = rh * rw, nk = G.wsh * G.wsw;
-    const int qbase = blockIdx.z * (64 * QT);
+    const int qbase = z_ * (64 * QT);
     if (qbase >= nq) return;  // uniform for the workgroup, before any barrier
 
     const T* __restrict__ qkv = static_cast<const T*>(p.qkv);
@@ -1142,9 +1150,10 @@ static int attn4_launch(const AttnArgs& a, hipStream_t s) {
 static int attn2_wide_launch(const AttnArgs& a, int max_nq, hipStream_t s) {
     const WinGeom G = make_geom(a.H, a.W, a.ws, a.pool);
     const float c = (1.0f / sqrtf((float)a.hd)) * 1.4426950408889634f;
-    const dim3 grid(a.N * G.nwy * G.nwx, a.nh, cdiv(max_nq, 128)), blk(256);
-    if (a.hd <= 80) hipLaunchKernelGGL((attn2_fwd_kernel<2, false, 3, 5>), grid, blk, 0, s, a, c);
-    else hipLaunchKernelGGL((attn2_fwd_kernel<2, false, 3, 6>), grid, blk, 0, s, a, c);
+    const int nqb = cdiv(max_nq, 128);
+    const dim3 grid(8 * cdiv(a.N * G.nwy * G.nwx, 8) * a.nh * nqb), blk(256);   // see the kernel: XCD-aware 1-D order
+    if (a.hd <= 80) hipLaunchKernelGGL((attn2_fwd_kernel<2, false, 3, 5>), grid, blk, 0, s, a, c, nqb);
+    else hipLaunchKernelGGL((attn2_fwd_kernel<2, false, 3, 6>), grid, blk, 0, s, a, c, nqb);
     LSAM_LAUNCH_CHECK();
     return LSAM_OK;
 }
@@ -1152,9 +1161,9 @@ static int attn2_wide_launch(const AttnArgs& a, int max_nq, hipStream_t s) {
 template <int QT> static int attn2_launch(const AttnArgs& a, int nqb, hipStream_t s) {
     const WinGeom G = make_geom(a.H, a.W, a.ws, a.pool);
     const float c = (1.0f / sqrtf((float)a.hd)) * 1.4426950408889634f;
-    const dim3 grid(a.N * G.nwy * G.nwx, a.nh, nqb), blk(256);
-    if (a.hd % 8 == 0 && a.hd <= 56) hipLaunchKernelGGL((attn2_fwd_kernel<QT, true>), grid, blk, 0, s, a, c);
-    else hipLaunchKernelGGL((attn2_fwd_kernel<QT, false>), grid, blk, 0, s, a, c);
+    const dim3 grid(8 * cdiv(a.N * G.nwy * G.nwx, 8) * a.nh * nqb), blk(256);   // see the kernel: XCD-aware 1-D order
+    if (a.hd % 8 == 0 && a.hd <= 56) hipLaunchKernelGGL((attn2_fwd_kernel<QT, true>), grid, blk, 0, s, a, c, nqb);
+    else hipLaunchKernelGGL((attn2_fwd_kernel<QT, false>), grid, blk, 0, s, a, c, nqb);
     LSAM_LAUNCH_CHECK();
     return LSAM_OK;
 }
