@@ -1,17 +1,27 @@
-"""Summarise a rocprofv3 kernel_trace.csv: per kernel (and grid) totals per step. usage: prof_summary.py trace.csv nsteps"""
+"""Summarise a rocprofv3 kernel_trace.csv of `bench.py --steps K --warmup W` (config 1): per kernel (and grid) totals per step over
+the K TIMED steps only -- the W warm-up steps (with the one-off weight packing) and the live-profiled steps behind the timed
+region are cut away by locating every step's first kernel (the PatchEmbed convolution).
+usage: prof_summary.py trace.csv K W ["header line"]"""
 import collections, csv, re, sys
-rows = list(csv.DictReader(open(sys.argv[1])))
-nsteps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+K, W = int(sys.argv[2]), int(sys.argv[3])
+starts = [i for i, r in enumerate(rows) if "patch_embed_kernel" in r["Kernel_Name"]]
+assert len(starts) > W + K, (len(starts), W, K)
+sel = rows[starts[W]:starts[W + K]]
+wall = int(rows[starts[W + K]]["Start_Timestamp"]) - int(rows[starts[W]]["Start_Timestamp"])
 g = collections.OrderedDict()
-tot = 0
-for r in rows:
-    n = r['Kernel_Name']
-    n = re.sub(r'\(.*', '', n)[:70]
-    key = (n, r['Grid_Size_X'], r['Workgroup_Size_X'])
-    d = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+tot = lsam = 0
+for r in sel:
+    n = re.sub(r"\(.*", "", r["Kernel_Name"])[:70]
+    key = (n, r["Grid_Size_X"], r["Workgroup_Size_X"])
+    d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     g.setdefault(key, []).append(d)
     tot += d
-items = sorted(g.items(), key=lambda kv: -sum(kv[1]))
-print(f"total GPU ms/step {tot/nsteps/1e6:.2f}")
-for k, v in items[:45]:
-    print(f"{sum(v)/nsteps/1e6:8.3f} ms/step  n/step {len(v)/nsteps:6.1f}  avg {sum(v)/len(v)/1e3:8.1f} us  {k}")
+    if "lsam" in n:
+        lsam += d
+if len(sys.argv) > 4:
+    print(sys.argv[4])
+print(f"{K} timed steps ({len(sel) / K:.1f} kernels per step): first kernel to first kernel {wall / K / 1e6:.3f} ms/step; kernel durations "
+      f"{tot / K / 1e6:.3f} ms/step, of which liblsam {lsam / K / 1e6:.3f} and torch (loss, optimizer, fills) {(tot - lsam) / K / 1e6:.3f}")
+for k, v in sorted(g.items(), key=lambda kv: -sum(kv[1]))[:48]:
+    print(f"{sum(v) / K / 1e6:8.3f} ms/step  n/step {len(v) / K:6.1f}  avg {sum(v) / len(v) / 1e3:8.1f} us  {k}")
