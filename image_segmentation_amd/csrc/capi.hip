@@ -148,6 +148,15 @@ int lsam_lateral_conv_fwd(const float* x, const void* image, const float* bias, 
     return launch_lateral(x, image, bias, out, M, in_channels, out_channels, static_cast<hipStream_t>(stream));
 }
 
+size_t lsam_stream_linear_image_bytes(int in_features, int out_features) { return streamlin_image_bytes(in_features, out_features); }
+int lsam_stream_linear_pack(const float* weight, int in_features, int out_features, void* image, lsam_stream_t stream) {
+    return launch_pack_streamlin(weight, in_features, out_features, image, static_cast<hipStream_t>(stream));
+}
+int lsam_stream_linear_fwd(const void* A, int lda, const void* image, const float* bias, void* out, int ldo, int M,
+                           int in_features, int out_features, lsam_stream_t stream) {
+    return launch_streamlin(A, lda, image, bias, out, ldo, M, in_features, out_features, static_cast<hipStream_t>(stream));
+}
+
 size_t lsam_neck_conv_image_bytes(int dtype, int in_channels, int out_channels) {
     return neck_image_bytes(in_channels, out_channels, dtype == LSAM_BF16 ? 2 : 4);
 }

@@ -24,6 +24,9 @@ namespace lsam {
 
 constexpr int AUG = 32;       // extra K columns: [q part 16 | v part 16]
 constexpr int PATCH_K = 160;  // 3*7*7 = 147 padded to a multiple of 16
+#ifndef STREAMLIN
+#define STREAMLIN 1           // K <= 224 qkv projections on the LDS-resident-weight streaming kernel (0: the tiled GEMM)
+#endif
 #ifndef MERGE_POOLED
 #define MERGE_POOLED 1        // a stage-entry block's shortcut and pooled queries from ONE pooled GEMM (0: two launches)
 #endif
@@ -45,6 +48,8 @@ struct BlockOff {
     size_t mimg, mbias;  // fused MLP weight image + fc2 bias (mlpblock.hip), if g.fused_mlp
     size_t timg, tvec;   // fused tail weight stream + packed vectors (tailblock.hip), if g.fused_tail
     size_t kvimg;        // k | v weight image of the fused projection + attention kernel (kvattn.hip), if g.fused_kv
+    size_t simg;         // small-K qkv (or k | v) projection with LDS-resident weights (lateral.hip: streamlin), rows simg_n0 .. + simg_n
+    int simg_n0, simg_n; // of the qkv weight; simg_n == 0: not built
 };
 
 }  // namespace lsam
@@ -239,6 +244,8 @@ static int pack_t(lsam_hiera* h, const lsam_block_params_t* bp, const float* pat
                                            p.fc2_b, q, at<char>(arena, o.timg), at<float>(arena, o.tvec), s));
         if (g.fused_kv)
             LSAM_TRY(launch_pack_kvattn(p.qkv_w, p.qkv_b, d, g.heads, q / g.heads, at<char>(arena, o.kvimg), s));
+        if (o.simg_n > 0)
+            LSAM_TRY(launch_pack_streamlin(static_cast<const float*>(p.qkv_w) + (size_t)o.simg_n0 * d, d, o.simg_n, at<char>(arena, o.simg), s));
         if (g.lora) {  // transposed copies for dX = dY . W   (frozen: no dW GEMMs exist)
             LSAM_TRY(launch_pack_matrix<T>(p.fc2_w, 1, 4 * q, 4 * q, q, at<T>(arena, o.w2T), q, s));
             LSAM_TRY(launch_pack_matrix<T>(p.fc1_w, 1, q, q, 4 * q, at<T>(arena, o.w1T), 4 * q, s));
@@ -360,9 +367,16 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
                 gq.pool_w = g.gin;
                 LSAM_TRY(launch_gemm<T>(gq, s));
             }
-            if (!g.fused_kv)
-                LSAM_TRY(linear<T>(xn, g.kq, at<T>(arena, o.wqkv) + (size_t)q * g.kq, g.kq, at<float>(arena, o.bqkv) + q, nullptr, 0,
-                                   0, nullptr, 0, qkv + q, 3 * q, nullptr, 0, 0, Mi, 2 * q, g.kq, s));
+            if (!g.fused_kv) {
+                if (o.simg_n == 2 * q && o.simg_n0 == q)
+                    LSAM_TRY(launch_streamlin(xn, g.kq, at<char>(arena, o.simg), at<float>(arena, o.bqkv) + q, qkv + q, 3 * q, Mi, d, 2 * q, s));
+                else
+                    LSAM_TRY(linear<T>(xn, g.kq, at<T>(arena, o.wqkv) + (size_t)q * g.kq, g.kq, at<float>(arena, o.bqkv) + q, nullptr, 0,
+                                       0, nullptr, 0, qkv + q, 3 * q, nullptr, 0, 0, Mi, 2 * q, g.kq, s));
+            }
+        } else if (o.simg_n == 3 * q && o.simg_n0 == 0) {
+            // K <= 224: all epilogue in the tiled GEMM; here the weights stay in LDS and the waves stream rows independently
+            LSAM_TRY(launch_streamlin(xn, g.kq, at<char>(arena, o.simg), at<float>(arena, o.bqkv), qkv, 3 * q, Mi, d, 3 * q, s));
         } else {
             LSAM_TRY(linear<T>(xn, g.kq, at<T>(arena, o.wqkv), g.kq, at<float>(arena, o.bqkv), nullptr, 0, 0, nullptr, 0,
                                qkv, 3 * q, nullptr, 0, 0, Mi, 3 * q, g.kq, s));
@@ -644,6 +658,17 @@ int lsam_hiera_create(const lsam_hiera_config_t* c, lsam_hiera_t** out) {
             o.tvec = b.take(tailblock_vec_floats(g.dout) * 4);
         }
         if (g.fused_kv) o.kvimg = b.take(kvattn_image_bytes());
+        if (c->dtype == LSAM_BF16 && STREAMLIN && !g.lora && !g.fused_attn && g.kq == g.dim) {
+            // which rows of the qkv weight the block's projection GEMM multiplies: all of them, or k | v only when the pooled
+            // queries come from the pooling epilogue (the plan-time part of forward_t's `qpooled`) and no fused k | v kernel runs
+            const bool kv_only = g.pool == 2 && d != q && (q / g.heads) % 8 == 0 && gemm_pool_supported(g.gin, g.gin, (int)q) && (2 * q) % 224 == 0;
+            const int n0 = kv_only ? (int)q : 0, n = (int)(3 * q) - n0;
+            if (!(kv_only && g.fused_kv) && streamlin_supported((int)d, n)) {
+                o.simg = b.take(streamlin_image_bytes((int)d, n));
+                o.simg_n0 = n0;
+                o.simg_n = n;
+            }
+        }
         if (g.lora) {
             o.w2T = b.take(4 * q * q * e);
             o.w1T = b.take(4 * q * q * e);

@@ -100,6 +100,12 @@ size_t lateral_image_bytes(int K, int N);
 int launch_pack_lateral(const float* w, int K, int N, void* img, hipStream_t s);
 int launch_lateral(const float* x, const void* img, const float* bias, void* out, int M, int K, int N, hipStream_t s);
 
+// small-K projection with LDS-resident weights, bf16 in / bf16 out + bias (lateral.hip): the stage-2 qkv / k | v Linears
+bool streamlin_supported(int K, int N);
+size_t streamlin_image_bytes(int K, int N);
+int launch_pack_streamlin(const float* w, int K, int N, void* img, hipStream_t s);   // w fp32 [N][K] row-major
+int launch_streamlin(const void* A, int lda, const void* img, const float* bias, void* out, int ldo, int M, int K, int N, hipStream_t s);
+
 // FPN neck level: lateral 1x1 conv (+ nearest-x2 top-down add) from the fp32 stage output, T out (neck.hip)
 bool neck_level_supported(int K, int N);
 size_t neck_image_bytes(int K, int N, size_t esz);

@@ -325,6 +325,32 @@ def lateral_conv(x2d: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor):
     return lateral_conv_fwd(x2d, lateral_conv_pack(weight), bias, weight.shape[0])
 
 
+def stream_linear_pack(weight: torch.Tensor) -> torch.Tensor:
+    """Linear(K <= 224, N) weight -> the LDS-resident bf16 weight image of lsam_stream_linear_fwd."""
+    _need_gpu(weight)
+    n, k = weight.shape
+    nbytes = lib().lsam_stream_linear_image_bytes(k, n)
+    if nbytes == 0:
+        raise _C.LsamError(f"stream linear: {k} -> {n} features not supported")
+    img = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    w = _f32c(weight)
+    check(lib().lsam_stream_linear_pack(ptr(w), k, n, ptr(img), stream()))
+    return img
+
+
+def stream_linear_fwd(A: torch.Tensor, img: torch.Tensor, bias: torch.Tensor, k: int, n: int, out: Optional[torch.Tensor] = None):
+    """bf16 [M, n] = A[:, :k] (bf16) @ W.T + bias with the weights resident in LDS (see lsam_stream_linear_fwd)."""
+    _need_gpu(A, img, bias)
+    assert A.dtype == torch.bfloat16
+    M, _, lda = _rows2d(A)
+    b = _f32c(bias)
+    if out is None:
+        out = torch.empty(M, n, dtype=torch.bfloat16, device=A.device)
+    _, _, ldo = _rows2d(out)
+    check(lib().lsam_stream_linear_fwd(ptr(A), lda, ptr(img), ptr(b), ptr(out), ldo, M, k, n, stream()))
+    return out
+
+
 def patch_embed_pack(proj_w):
     """PatchEmbed proj.weight [E,3,7,7] fp32 -> fragment-order bf16 weight image of the direct convolution."""
     _need_gpu(proj_w)

@@ -165,6 +165,19 @@ int lsam_lateral_conv_pack(const float* weight, int in_channels, int out_channel
 int lsam_lateral_conv_fwd(const float* x, const void* image, const float* bias, void* out, int M, int in_channels,
                           int out_channels, lsam_stream_t stream);
 
+/* A Linear with a SMALL input width and LDS-resident weights, bf16 MFMA, bf16 in / bf16 out:
+ *   out[m][:out_features] = A[m][:in_features] . weight^T + bias
+ * (the qkv Linear of MultiScaleAttention, hieradet.py:59, in the stages where dim <= 224 -- Hiera-B+ stage 2, Hiera-L stage 1 --
+ * and the k | v rows of it in a q-pool block whose queries come from lsam_linear_maxpool2x2, hieradet.py:64-67).
+ * For such widths the tiled lsam_linear is all epilogue (3.5 k-tiles in front of 128 store instructions per output tile);
+ * here each 224-column group of the weight stays in LDS and every wave streams its own 64-row groups with no barrier.
+ * weight fp32 [out_features][in_features] row-major; A bf16 [M][lda]; out bf16 [M][ldo]; lda, ldo multiples of 8.
+ * in_features % 8 == 0, 16 <= in_features <= 224, out_features % 32 == 0; otherwise 0 bytes / LSAM_ERR_UNSUPPORTED. */
+size_t lsam_stream_linear_image_bytes(int in_features, int out_features);
+int lsam_stream_linear_pack(const float* weight, int in_features, int out_features, void* image, lsam_stream_t stream);
+int lsam_stream_linear_fwd(const void* A, int lda, const void* image, const float* bias, void* out, int ldo, int M,
+                           int in_features, int out_features, lsam_stream_t stream);
+
 /* One FPN level in one kernel, any level and both dtypes (FpnNeck.forward, image_encoder.py:102-134):
  *   out[n][y][x][:] = T( Conv2d(in_channels, out_channels, 1)(x)[n, :, y, x]  (+ top[n][y/2][x/2][:]) )
  * = the lateral convolution `self.convs[n - i](x)` (:112-114) with, when top != NULL, the nearest-x2 top-down add

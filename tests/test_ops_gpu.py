@@ -576,6 +576,31 @@ def test_linear_skinny32(dt, M, K):
     assert o32.dtype == torch.float32 and rel_err(o32.double(), ref) < (1e-6 if dt == torch.float32 else 1e-5 + 0)
 
 
+@pytest.mark.parametrize("M,K,N", [(262144 // 8, 224, 672), (70001, 224, 896), (5000, 112, 448), (64, 144, 432 + 16), (1, 16, 32),
+                                   (33000, 200, 1344), (4097, 224, 64)])
+def test_stream_linear(M, K, N):
+    """The small-K Linear with LDS-resident weights (stage-2 qkv, hieradet.py:59): one / several / partial column groups,
+    ragged row counts, operands and results inside wider buffers (the plan writes k | v behind the q columns), and the
+    same bits as lsam_linear (bias first, k-steps in order)."""
+    from image_segmentation_amd import ops
+    g = torch.Generator().manual_seed(M + K + N)
+    abuf = torch.randn(M, K + 24, generator=g).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    obuf = torch.full((M, N + 40), 7.0, dtype=torch.bfloat16, device="cuda")
+    a = abuf[:, :K]
+    img = ops.stream_linear_pack(w)
+    out = ops.stream_linear_fwd(a, img, b, K, N, out=obuf[:, 8:8 + N])
+    ref = a.double() @ w.bfloat16().double().t() + b.double()
+    assert rel_err(out.double(), ref) < 5e-3
+    assert (obuf[:, :8] == 7.0).all() and (obuf[:, 8 + N:] == 7.0).all()          # nothing outside the N columns is written
+    tiled = ops.linear(a, ops.pack_matrix(w, torch.bfloat16), b, K=K)
+    if M >= 1024 and N % 224 == 0:      # the persistent tiled kernels seed their accumulators with the bias too: the same sums in the same order
+        assert torch.equal(out, tiled)
+    else:              # (the generic small-M kernel adds the bias last)
+        assert rel_err(out.double(), tiled.double()) < 4e-3
+
+
 @pytest.mark.parametrize("M,N,K,few", [(1040, 32, 44, False), (2048, 32, 900, False), (37, 48, 12, True), (130, 256, 260, True),
                                        (16, 8, 4, True)])
 def test_linear_streaming_fp32_k_not_multiple_of_8(M, N, K, few):
