@@ -60,6 +60,7 @@ KERNEL_NAMES = {
     9224: ("tail<7,14> stage-2 block tail (224 wide)", "flop"),
     2224: ("gemm3 256x224 persistent bf16 GEMM, bf16 out", "flop"),
     2225: ("gemm3 256x224 persistent bf16 GEMM, fp32 out", "flop"),
+    5004: ("qkvattn4: qkv (k | v) projection + 4x4-window attention in one kernel (stage 2)", "flop"),
     2016: ("streamlin: small-K Linear, weights resident in LDS, rows streamed", "flop"),
     2226: ("gemm3 256x224 persistent bf16 GEMM, column-guarded (N % 224 != 0), bf16 out", "flop"),
     2227: ("gemm3 256x224 persistent bf16 GEMM, column-guarded (N % 224 != 0), fp32 out", "flop"),

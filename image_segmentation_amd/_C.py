@@ -130,6 +130,10 @@ def lib() -> C.CDLL:
         L.lsam_neck_conv_split_image_bytes.argtypes = [i, i]
         L.lsam_neck_conv_pack_split.argtypes = [vp, i, i, vp, vp]
         L.lsam_neck_level_fwd_split.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp]
+        L.lsam_qkv_window4_attention_image_bytes.restype = C.c_size_t
+        L.lsam_qkv_window4_attention_image_bytes.argtypes = [i, i, i, i]
+        L.lsam_qkv_window4_attention_pack.argtypes = [vp, vp, i, i, i, i, vp, vp]
+        L.lsam_qkv_window4_attention_fwd.argtypes = [vp, i, vp, i, vp, vp, i, i, i, i, i, i, i, vp]
         L.lsam_stream_linear_image_bytes.restype = C.c_size_t
         L.lsam_stream_linear_image_bytes.argtypes = [i, i]
         L.lsam_stream_linear_pack.argtypes = [vp, i, i, vp, vp]
@@ -190,6 +194,7 @@ EXPORTED = [
     "lsam_neck_topdown_bwd", "lsam_act_bwd", "lsam_mha_bwd", "lsam_upscale2x2_bwd", "lsam_mask_gate_bwd", "lsam_bilinear_upsample_bwd",
     "lsam_batched_outer_ws_floats", "lsam_batched_outer", "lsam_mask_loss_ws_floats", "lsam_mask_loss_sums", "lsam_mask_loss_bwd", "lsam_kv_window_attention_image_bytes", "lsam_kv_window_attention_pack", "lsam_kv_window_attention_fwd",
     "lsam_neck_conv_split_image_bytes", "lsam_neck_conv_pack_split", "lsam_neck_level_fwd_split",
+    "lsam_qkv_window4_attention_image_bytes", "lsam_qkv_window4_attention_pack", "lsam_qkv_window4_attention_fwd",
     "lsam_stream_linear_image_bytes", "lsam_stream_linear_pack", "lsam_stream_linear_fwd",
     "lsam_outer_reduce_static_max_ws", "lsam_outer_reduce_static_init", "lsam_outer_reduce_static",
 ]

@@ -205,6 +205,20 @@ int lsam_kv_window_attention_fwd(const void* xn, int ldx, const float* q_pooled,
     return launch_kvattn(a, static_cast<hipStream_t>(stream));
 }
 
+size_t lsam_qkv_window4_attention_image_bytes(int dim, int nh, int hd, int pooled_q) {
+    return qkvattn4_supported(4, 4, 4, pooled_q ? 2 : 1, nh, hd, dim, pooled_q ? nh * hd : dim) ? qkvattn4_image_bytes(nh, pooled_q != 0) : 0;
+}
+int lsam_qkv_window4_attention_pack(const float* qkv_w, const float* qkv_b, int dim, int nh, int hd, int pooled_q, void* image,
+                                    lsam_stream_t stream) {
+    return launch_pack_qkvattn4(qkv_w, qkv_b, dim, nh, hd, pooled_q != 0, image, static_cast<hipStream_t>(stream));
+}
+int lsam_qkv_window4_attention_fwd(const void* xn, int ldx, const float* q_pooled, int ldq, const void* image, void* out, int ldo,
+                                   int N, int H, int W, int dim, int nh, int hd, lsam_stream_t stream) {
+    QkvAttn4Args a{static_cast<const bf16*>(xn), ldx, q_pooled, ldq, static_cast<const char*>(image), static_cast<bf16*>(out), ldo,
+                   N, H, W, dim, nh, hd, (1.0f / sqrtf((float)hd)) * 1.4426950408889634f};
+    return launch_qkvattn4(a, static_cast<hipStream_t>(stream));
+}
+
 size_t lsam_window_block_image_bytes(int nh) { return (nh == 1 || nh == 2) ? winblock_image_bytes(nh) : 0; }
 size_t lsam_window_block_bias_floats(int nh) { return (nh == 1 || nh == 2) ? winblock_bias_floats(nh) : 0; }
 int lsam_window_block_pack(const float* qkv_w, const float* qkv_b, const float* proj_w, const float* proj_b, int nh,

@@ -24,6 +24,9 @@ namespace lsam {
 
 constexpr int AUG = 32;       // extra K columns: [q part 16 | v part 16]
 constexpr int PATCH_K = 160;  // 3*7*7 = 147 padded to a multiple of 16
+#ifndef QKVATTN4
+#define QKVATTN4 1            // 4x4-window blocks: qkv (or k | v) projection inside the attention kernel (0: projection GEMM + attention)
+#endif
 #ifndef STREAMLIN
 #define STREAMLIN 1           // K <= 224 qkv projections on the LDS-resident-weight streaming kernel (0: the tiled GEMM)
 #endif
@@ -38,6 +41,7 @@ struct BlockGeom {
     bool fused_attn;  // bf16 only: LN1 + qkv + window attention + proj + residual in one kernel (winblock.hip)
     bool fused_mlp;   // bf16 only: LN2 + fc1 + GELU + fc2 + residual in one kernel (mlpblock.hip)
     bool fused_tail;  // bf16 only: proj + residual + LN2 + MLP + residual (+ next block's LN1) in one kernel (tailblock.hip)
+    bool fused_qkv4;  // bf16 only: qkv (k | v for a q-pool block) projection + 4x4-window attention in one kernel (qkvattn.hip)
     bool fused_kv;    // bf16 only: k | v projection + 8x8-window attention of a q-pool stage-entry block in one kernel (kvattn.hip)
 };
 struct BlockOff {
@@ -48,6 +52,7 @@ struct BlockOff {
     size_t mimg, mbias;  // fused MLP weight image + fc2 bias (mlpblock.hip), if g.fused_mlp
     size_t timg, tvec;   // fused tail weight stream + packed vectors (tailblock.hip), if g.fused_tail
     size_t kvimg;        // k | v weight image of the fused projection + attention kernel (kvattn.hip), if g.fused_kv
+    size_t qaimg;        // weight image of the fused projection + 4x4-window attention kernel (qkvattn.hip), if g.fused_qkv4
     size_t simg;         // small-K qkv (or k | v) projection with LDS-resident weights (lateral.hip: streamlin), rows simg_n0 .. + simg_n
     int simg_n0, simg_n; // of the qkv weight; simg_n == 0: not built
 };
@@ -244,6 +249,8 @@ static int pack_t(lsam_hiera* h, const lsam_block_params_t* bp, const float* pat
                                            p.fc2_b, q, at<char>(arena, o.timg), at<float>(arena, o.tvec), s));
         if (g.fused_kv)
             LSAM_TRY(launch_pack_kvattn(p.qkv_w, p.qkv_b, d, g.heads, q / g.heads, at<char>(arena, o.kvimg), s));
+        if (g.fused_qkv4)
+            LSAM_TRY(launch_pack_qkvattn4(p.qkv_w, p.qkv_b, d, g.heads, q / g.heads, g.pool == 2, at<char>(arena, o.qaimg), s));
         if (o.simg_n > 0)
             LSAM_TRY(launch_pack_streamlin(static_cast<const float*>(p.qkv_w) + (size_t)o.simg_n0 * d, d, o.simg_n, at<char>(arena, o.simg), s));
         if (g.lora) {  // transposed copies for dX = dY . W   (frozen: no dW GEMMs exist)
@@ -359,6 +366,8 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
         }
         // ---- qkv (+LoRA through the augmented K columns) ------------------------------------------
         T* qkv = grad ? at<T>(ws, w.sv[gi].qkv) : at<T>(ws, w.qkv);
+        // 4x4 windows: a window is one MFMA tile and a wave projects, scores and mixes it in registers (no qkv in memory)
+        const bool use_qa4 = g.fused_qkv4 && (g.pool == 1 || qpooled);
         if (qpooled) {
             if (!q_done) {
                 GemmArgs gq{xn, g.kq, at<T>(arena, o.wqkv), g.kq, at<float>(arena, o.bqkv), nullptr, 0, 0, nullptr, 0, qp, q,
@@ -367,13 +376,14 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
                 gq.pool_w = g.gin;
                 LSAM_TRY(launch_gemm<T>(gq, s));
             }
-            if (!g.fused_kv) {
+            if (!g.fused_kv && !use_qa4) {
                 if (o.simg_n == 2 * q && o.simg_n0 == q)
                     LSAM_TRY(launch_streamlin(xn, g.kq, at<char>(arena, o.simg), at<float>(arena, o.bqkv) + q, qkv + q, 3 * q, Mi, d, 2 * q, s));
                 else
                     LSAM_TRY(linear<T>(xn, g.kq, at<T>(arena, o.wqkv) + (size_t)q * g.kq, g.kq, at<float>(arena, o.bqkv) + q, nullptr, 0,
                                        0, nullptr, 0, qkv + q, 3 * q, nullptr, 0, 0, Mi, 2 * q, g.kq, s));
             }
+        } else if (use_qa4) {
         } else if (o.simg_n == 3 * q && o.simg_n0 == 0) {
             // K <= 224: all epilogue in the tiled GEMM; here the weights stay in LDS and the waves stream rows independently
             LSAM_TRY(launch_streamlin(xn, g.kq, at<char>(arena, o.simg), at<float>(arena, o.bqkv), qkv, 3 * q, Mi, d, 3 * q, s));
@@ -383,7 +393,13 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
         }
         // ---- attention ------------------------------------------------------------------------------
         T* a = at<T>(ws, w.a);
-        if (qpooled && g.fused_kv) {
+        if (use_qa4) {
+            if constexpr (sizeof(T) == 2) {
+                QkvAttn4Args qa{xn, g.kq, qp, q, at<char>(arena, o.qaimg), a, q, N, g.gin, g.gin, d, g.heads, q / g.heads,
+                                (1.0f / sqrtf((float)(q / g.heads))) * 1.4426950408889634f};
+                LSAM_TRY(launch_qkvattn4(qa, s));
+            }
+        } else if (qpooled && g.fused_kv) {
             // k | v of the window's 64 tokens are projected inside the attention kernel: they never cross HBM
             if constexpr (sizeof(T) == 2) {
                 KvAttnArgs ka{xn, g.kq, qp, q, at<char>(arena, o.kvimg), a, q, N, g.gin, g.gin, d, q / g.heads,
@@ -585,6 +601,9 @@ int lsam_hiera_create(const lsam_hiera_config_t* c, lsam_hiera_t** out) {
         g.fused_kv = c->dtype == LSAM_BF16 && !g.lora && g.dim != g.dout && g.dout % g.heads == 0 &&
                      kvattn_supported(g.gin, g.gin, g.ws, g.pool, g.heads, g.dout / g.heads, g.dim, g.dout) &&
                      gemm_pool_supported(g.gin, g.gin, g.dout) && (2 * g.dout) % 224 == 0;
+        g.fused_qkv4 = QKVATTN4 && c->dtype == LSAM_BF16 && !g.lora && !g.fused_attn && !g.fused_kv && g.dout % g.heads == 0 &&
+                       qkvattn4_supported(g.gin, g.gin, g.ws, g.pool, g.heads, g.dout / g.heads, g.dim, g.dout) &&
+                       (g.pool == 1 || (g.dim != g.dout && gemm_pool_supported(g.gin, g.gin, g.dout) && (2 * g.dout) % 224 == 0));
         h->blk.push_back(g);
         dim = g.dout;
         grid = g.gout;
@@ -658,7 +677,8 @@ int lsam_hiera_create(const lsam_hiera_config_t* c, lsam_hiera_t** out) {
             o.tvec = b.take(tailblock_vec_floats(g.dout) * 4);
         }
         if (g.fused_kv) o.kvimg = b.take(kvattn_image_bytes());
-        if (c->dtype == LSAM_BF16 && STREAMLIN && !g.lora && !g.fused_attn && g.kq == g.dim) {
+        if (g.fused_qkv4) o.qaimg = b.take(qkvattn4_image_bytes(g.heads, g.pool == 2));
+        if (c->dtype == LSAM_BF16 && STREAMLIN && !g.lora && !g.fused_attn && !g.fused_qkv4 && g.kq == g.dim) {
             // which rows of the qkv weight the block's projection GEMM multiplies: all of them, or k | v only when the pooled
             // queries come from the pooling epilogue (the plan-time part of forward_t's `qpooled`) and no fused k | v kernel runs
             const bool kv_only = g.pool == 2 && d != q && (q / g.heads) % 8 == 0 && gemm_pool_supported(g.gin, g.gin, (int)q) && (2 * q) % 224 == 0;

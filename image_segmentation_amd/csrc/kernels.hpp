@@ -33,7 +33,7 @@ void prof_end(int rec, hipStream_t s, double flops, int cfg, int m, int n, int k
 enum {
     PROF_LN_FWD = 100, PROF_LN_BWD = 101, PROF_CAST = 102, PROF_LATERAL = 103, PROF_PATCH_EMBED = 104, PROF_WINBLOCK = 105,
     PROF_MLPBLOCK = 106, PROF_MAXPOOL = 107, PROF_SPATIAL_MEAN = 108, PROF_OUTER = 109, PROF_NECK = 110,
-    PROF_ATTN_SMALL = 111, PROF_KVATTN = 5003,                                      /* windows with <= 16 queries per wave: bytes */
+    PROF_ATTN_SMALL = 111, PROF_KVATTN = 5003, PROF_QKVATTN4 = 5004,                                      /* windows with <= 16 queries per wave: bytes */
     PROF_ATTN_GLOBAL = 5000, PROF_ATTN_WIN = 5001, PROF_ATTN_BWD = 5002   /* FLOPs */
 };
 struct ProfScope {
@@ -134,6 +134,26 @@ size_t kvattn_image_bytes();
 bool kvattn_supported(int H, int W, int ws, int pool, int nh, int hd, int dim, int dout);
 int launch_pack_kvattn(const float* wqkv, const float* bqkv, int dim, int nh, int hd, void* img, hipStream_t s);
 int launch_kvattn(const KvAttnArgs& a, hipStream_t s);
+
+// fused qkv (or k | v) projection + 4x4-window attention (qkvattn.hip): stage-2 blocks and the q-pool block behind them
+#ifndef QKVATTN4_TT
+#define QKVATTN4_TT 2   // windows per wave and pass
+#endif
+#ifndef QKVATTN4_NW
+#define QKVATTN4_NW 8   // waves per workgroup
+#endif
+struct QkvAttn4Args {
+    const bf16* xn; int ldx;      // LN1 output rows [N*H*W][dim]
+    const float* qp; int ldqp;    // nullptr: q projected here; else pooled queries, fp32 [N*(H/2)*(W/2)][nh*hd]
+    const char* img;              // launch_pack_qkvattn4 (packed for the same variant)
+    bf16* out; int ldo;           // attention output [N*H*W][nh*hd], or [N*(H/2)*(W/2)][nh*hd] with pooled queries
+    int N, H, W, dim, nh, hd;
+    float c_log2;                 // log2(e) / sqrt(hd)
+};
+size_t qkvattn4_image_bytes(int nh, bool poolq);
+bool qkvattn4_supported(int H, int W, int ws, int pool, int nh, int hd, int dim, int dout);
+int launch_pack_qkvattn4(const float* wqkv, const float* bqkv, int dim, int nh, int hd, bool poolq, void* img, hipStream_t s);
+int launch_qkvattn4(const QkvAttn4Args& a, hipStream_t s);
 
 // fused attention half of a same-dim 8x8-window block (winblock.hip)
 struct WinBlockArgs {

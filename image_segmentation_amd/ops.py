@@ -510,6 +510,39 @@ def kv_window_attention_fwd(xn: torch.Tensor, q_pooled: torch.Tensor, img: torch
     return out
 
 
+def qkv_window4_attention_pack(qkv_w: torch.Tensor, qkv_b: torch.Tensor, nh: int, pooled_q: bool = False) -> torch.Tensor:
+    """Weight image of qkv_window4_attention_fwd from qkv.weight [3*nh*hd, dim] and qkv.bias (k | v only with pooled_q)."""
+    _need_gpu(qkv_w, qkv_b)
+    w, b = _f32c(qkv_w), _f32c(qkv_b)
+    dim, hd = w.shape[1], w.shape[0] // (3 * nh)
+    nbytes = lib().lsam_qkv_window4_attention_image_bytes(dim, nh, hd, int(pooled_q))
+    if nbytes == 0:
+        raise _C.LsamError(f"qkv_window4_attention: {nh} heads of {hd} over {dim} channels not supported")
+    img = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    check(lib().lsam_qkv_window4_attention_pack(ptr(w), ptr(b), dim, nh, hd, int(pooled_q), ptr(img), stream()))
+    return img
+
+
+def qkv_window4_attention_fwd(xn: torch.Tensor, img: torch.Tensor, nh: int, hd: int, q_pooled: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """4x4-window attention with the projection inside the kernel (see lsam_qkv_window4_attention_fwd): xn bf16 [N, H, W, dim];
+    without q_pooled bf16 [N, H, W, nh*hd] from qkv = xn . W^T + b; with q_pooled (fp32 [N, H/2, W/2, nh*hd]) bf16
+    [N, H/2, W/2, nh*hd] from k | v = xn . W_kv^T + b_kv and the window's four pooled queries."""
+    _need_gpu(xn, img)
+    assert xn.dtype == torch.bfloat16 and xn.is_contiguous() and xn.dim() == 4
+    N, H, W, dim = xn.shape
+    q = nh * hd
+    if q_pooled is None:
+        out = torch.empty(N, H, W, q, dtype=torch.bfloat16, device=xn.device)
+        qp, ldq = None, 0
+    else:
+        _need_gpu(q_pooled)
+        assert q_pooled.dtype == torch.float32 and q_pooled.is_contiguous() and tuple(q_pooled.shape) == (N, H // 2, W // 2, q)
+        out = torch.empty(N, H // 2, W // 2, q, dtype=torch.bfloat16, device=xn.device)
+        qp, ldq = ptr(q_pooled), q
+    check(lib().lsam_qkv_window4_attention_fwd(ptr(xn), dim, qp, ldq, ptr(img), ptr(out), q, N, H, W, dim, nh, hd, stream()))
+    return out
+
+
 # ---- SAM heads pieces (csrc/heads.hip) ---------------------------------------------------------------------------
 def add_rows(a: torch.Tensor, b: Optional[torch.Tensor], out_dtype: torch.dtype) -> torch.Tensor:
     """out[m] = a[m] + b[m % rows(b)] as out_dtype; a fp32 / bf16 [M, C] (row-major), b fp32 [R, C] or None (a cast)."""

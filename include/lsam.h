@@ -219,6 +219,20 @@ int lsam_kv_window_attention_pack(const float* qkv_w, const float* qkv_b, int di
 int lsam_kv_window_attention_fwd(const void* xn, int ldx, const float* q_pooled, int ldq, const void* image, void* out, int ldo,
                                  int N, int H, int W, int dim, int nh, int hd, lsam_stream_t stream);
 
+/* Attention half of a block with 4x4 windows (MultiScaleAttention.forward, hieradet.py:56-81; Hiera-B+ stage 2: 224
+ * channels, 4 heads of 56) in one kernel: qkv = norm1(x) . W^T + b (hieradet.py:59) for the 16 tokens of a window and
+ * softmax(q k^T / sqrt(hd)) v per head (:73-77); qkv (352 MB per 16-frame batch and block) never exists in memory.
+ * q_pooled == NULL: dim == nh * hd, out bf16 [N*H*W][ldo].  q_pooled != NULL: the q-pool stage-entry block behind them
+ * (q = do_pool(q), :69-71; B+ block 5: 224 -> 448 channels, 8 heads): k | v projected here, q_pooled fp32
+ * [N*(H/2)*(W/2)][ldq] as lsam_linear_maxpool2x2 produces it, out bf16 [N*(H/2)*(W/2)][ldo].  xn bf16 [N*H*W][ldx] (norm1
+ * output).  image: lsam_qkv_window4_attention_pack(qkv.weight [3*nh*hd][dim], qkv.bias) with the same pooled_q flag.
+ * bf16, hd % 8 == 0 and <= 64, dim % 8 == 0 and <= 224, H and W multiples of 4 (image_bytes returns 0 otherwise). */
+size_t lsam_qkv_window4_attention_image_bytes(int dim, int nh, int hd, int pooled_q);
+int lsam_qkv_window4_attention_pack(const float* qkv_w, const float* qkv_b, int dim, int nh, int hd, int pooled_q, void* image,
+                                    lsam_stream_t stream);
+int lsam_qkv_window4_attention_fwd(const void* xn, int ldx, const float* q_pooled, int ldq, const void* image, void* out, int ldo,
+                                   int N, int H, int W, int dim, int nh, int hd, lsam_stream_t stream);
+
 /* ---- SAM prompt encoder / mask decoder pieces (SAM2Base._forward_sam_heads, sam2_base.py:257-413) that are not a
  * Linear or a LayerNorm.  See image_segmentation_amd/sam_heads.py for the composition. ---- */
 /* out[m][c] = (T_out)(a[m][c] + b[m % b_rows][c]); b nullable (then a dtype conversion).  `queries + query_pe`,

@@ -557,6 +557,48 @@ def test_kv_window_attention_fused(N, H, W, dim, hd):
         ops.kv_window_attention_fwd(xn.cuda()[:, :, :W - 4].contiguous(), qp.cuda()[:, :, :W // 2 - 2].contiguous(), img, nh)
 
 
+@pytest.mark.parametrize("N,H,W,dim,nh,hd,pooled", [(2, 16, 24, 224, 4, 56, False), (1, 4, 4, 224, 4, 56, False),
+                                                    (3, 20, 12, 96, 2, 48, False), (1, 36, 28, 64, 1, 64, False),
+                                                    (2, 16, 24, 224, 8, 56, True), (1, 4, 4, 112, 4, 56, True),
+                                                    (3, 20, 12, 200, 3, 24, True)])
+def test_qkv_window4_attention_fused(N, H, W, dim, nh, hd, pooled):
+    """4x4-window blocks (hieradet.py:56-81; with do_pool(q) :69-71 for the stage-entry variant): qkv (or k | v) projected
+    inside the attention kernel, against a plain fp32 torch evaluation of the same block half from the same bf16 inputs.
+    Window counts that are not a multiple of the windows a wave takes per pass, one / two heads per workgroup."""
+    import torch.nn.functional as F
+    from image_segmentation_amd import ops
+    q = nh * hd
+    g = torch.Generator().manual_seed(dim + hd + H)
+    xn = torch.randn(N, H, W, dim, generator=g).bfloat16()
+    w = (torch.randn(3 * q, dim, generator=g) / dim ** 0.5).bfloat16().float()
+    b = 0.2 * torch.randn(3 * q, generator=g)
+    qkv = xn.float() @ w.t() + b                                             # [N, H, W, 3q]
+    qf, kf, vf = qkv[..., :q], qkv[..., q:2 * q].bfloat16().float(), qkv[..., 2 * q:].bfloat16().float()
+    def windows(t, ws):                                                      # [N, h, w, C] -> [N*nwin, ws*ws, nh, hd]
+        n, hh, ww, c = t.shape
+        t = t.view(n, hh // ws, ws, ww // ws, ws, nh, c // nh).permute(0, 1, 3, 2, 4, 5, 6)
+        return t.reshape(-1, ws * ws, nh, c // nh)
+    kw, vw = windows(kf, 4), windows(vf, 4)
+    img = ops.qkv_window4_attention_pack(w.cuda(), b.cuda(), nh, pooled_q=pooled)
+    if pooled:
+        qp = F.max_pool2d(qf.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).contiguous()   # do_pool(q)
+        qw = windows(qp.bfloat16().float(), 2)
+        o = F.scaled_dot_product_attention(qw.transpose(1, 2), kw.transpose(1, 2), vw.transpose(1, 2))   # [B, nh, 4, hd]
+        o = o.transpose(1, 2).reshape(N, H // 4, W // 4, 2, 2, q).permute(0, 1, 3, 2, 4, 5).reshape(N, H // 2, W // 2, q)
+        got = ops.qkv_window4_attention_fwd(xn.cuda(), img, nh, hd, q_pooled=qp.cuda())
+    else:
+        qw = windows(qf.bfloat16().float(), 4)
+        o = F.scaled_dot_product_attention(qw.transpose(1, 2), kw.transpose(1, 2), vw.transpose(1, 2))   # [B, nh, 16, hd]
+        o = o.transpose(1, 2).reshape(N, H // 4, W // 4, 4, 4, q).permute(0, 1, 3, 2, 4, 5).reshape(N, H, W, q)
+        got = ops.qkv_window4_attention_fwd(xn.cuda(), img, nh, hd)
+    assert got.dtype == torch.bfloat16 and got.shape == o.shape
+    assert rel_err(got.float(), o) < 1e-2
+    # unsupported geometries are refused, not rerouted
+    from image_segmentation_amd._C import LsamError
+    with pytest.raises(LsamError):
+        ops.qkv_window4_attention_fwd(xn.cuda()[:, :, :W - 2].contiguous(), img, nh, hd)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,K", [(16384, 896), (2000, 2688), (1030, 120), (1024, 40)])
 def test_linear_skinny32(dt, M, K):

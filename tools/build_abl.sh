@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../image_segmentation_amd/csrc"
 mkdir -p build_abl ../../tools/abl
 src=$1; shift
 objs=""
-for o in gemm norm_elem attention winblock mlpblock tailblock patchembed lateral neck heads heads_bwd kvattn hiera capi; do
+for o in gemm norm_elem attention winblock mlpblock tailblock patchembed lateral neck heads heads_bwd kvattn qkvattn hiera capi; do
   [ $o = $src ] || objs="$objs build/$o.o"
 done
 while [ $# -ge 2 ]; do
