@@ -121,13 +121,18 @@ def measured_trace():
     if best is None:
         return None
     try:
-        m = re.search(r"kernel durations ([\d.]+) ms/step, of which liblsam ([\d.]+) and torch[^\d]*([\d.]+)", open(best).read())
+        text = open(best).read()
     except OSError:
         return None
+    m = re.search(r"kernel durations ([\d.]+) ms/step, of which liblsam ([\d.]+) and torch[^\d]*([\d.]+)", text)
     if not m:
         return None
-    return {"file": os.path.relpath(best, REPO), "all_kernels_ms_per_step": float(m.group(1)), "liblsam_ms_per_step": float(m.group(2)),
-            "torch_ms_per_step": float(m.group(3))}
+    out = {"file": os.path.relpath(best, REPO), "all_kernels_ms_per_step": float(m.group(1)), "liblsam_ms_per_step": float(m.group(2)),
+           "torch_ms_per_step": float(m.group(3))}
+    d = re.search(r"avg\s+([\d.]+) us\s+\('void lsam::tailpair_kernel<14, 28", text)   # the roofline kernel in the same trace
+    if d:
+        out["tailpair_avg_launch_us"] = float(d.group(1))
+    return out
 
 
 def build(device, cfg=BPLUS, lora_rank=4):

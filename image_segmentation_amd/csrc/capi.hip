@@ -287,8 +287,8 @@ int lsam_prof_bracket_cost(lsam_stream_t stream, int pairs, float* host_avg_ms) 
     LSAM_REQUIRE(host_avg_ms && pairs > 0 && pairs <= 4096, LSAM_ERR_BAD_ARG, "prof_bracket_cost: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipEvent_t e0, e1;
-    LSAM_HIP(hipEventCreate(&e0));
-    LSAM_HIP(hipEventCreate(&e1));
+    LSAM_HIP(hipEventCreateWithFlags(&e0, hipEventDisableSystemFence));
+    LSAM_HIP(hipEventCreateWithFlags(&e1, hipEventDisableSystemFence));
     double sum = 0.0;
     int rc = LSAM_OK;
     for (int i = 0; i < pairs && rc == LSAM_OK; ++i) {

@@ -987,8 +987,8 @@ int prof_arm(int capacity) {
         LSAM_REQUIRE(n, LSAM_ERR_BAD_ARG, "prof: out of host memory");
         g_prof = n;
         for (int i = g_prof_cap; i < capacity; ++i) {
-            LSAM_HIP(hipEventCreate(&g_prof[i].e0));
-            LSAM_HIP(hipEventCreate(&g_prof[i].e1));
+            LSAM_HIP(hipEventCreateWithFlags(&g_prof[i].e0, hipEventDisableSystemFence));
+            LSAM_HIP(hipEventCreateWithFlags(&g_prof[i].e1, hipEventDisableSystemFence));
         }
         g_prof_cap = capacity;
     }
