@@ -75,8 +75,12 @@ __global__ void pack_winblock_kernel(const float* __restrict__ wqkv, const float
     }
 }
 
+#ifndef WINBLOCK_NW
+#define WINBLOCK_NW 4   // waves per workgroup (one workgroup per CU: the weight image fills the LDS)
+#endif
 template <int NH>
-__global__ __launch_bounds__(256, 1) void winblock_attn_kernel(const WinBlockArgs p) {
+__global__ __launch_bounds__(64 * WINBLOCK_NW, 1) void winblock_attn_kernel(const WinBlockArgs p) {
+    constexpr int NW = WINBLOCK_NW;
     using I = WinImg<NH>;
     constexpr int KS = 2 * NH;      // 32-wide k-steps over the model dim padded to 64 NH
     constexpr int NTO = 4 * NH;     // output column tiles of proj
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(256, 1) void winblock_attn_kernel(const WinBlockArg
     {
         const uint4* src = reinterpret_cast<const uint4*>(p.img);
         uint4* dst = reinterpret_cast<uint4*>(smem);
-        for (int i = tid; i < I::BYTES / 16; i += 256) dst[i] = src[i];
+        for (int i = tid; i < I::BYTES / 16; i += 64 * NW) dst[i] = src[i];
     }
     __syncthreads();
 
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256, 1) void winblock_attn_kernel(const WinBlockArg
     const float* __restrict__ bias_p = p.bias_p;
 
 #pragma unroll 1
-    for (int w = blockIdx.x * 4 + wave; w < nwin; w += gridDim.x * 4) {
+    for (int w = blockIdx.x * NW + wave; w < nwin; w += gridDim.x * NW) {
         const int n = w / (nwy * nwx), wi = w % (nwy * nwx);
         const int wy = wi / nwx, wx = wi % nwx;
         // token row of tile row t (0..63): (t / 8, t % 8) inside the window
@@ -390,8 +394,8 @@ template <int NH> static int launch_wb(const WinBlockArgs& a, hipStream_t s) {
         attr_set = true;
     }
     const int nwin = a.N * (a.H / 8) * (a.W / 8);
-    const int grid = nwin / 4 < 256 ? (nwin + 3) / 4 : 256;
-    hipLaunchKernelGGL(winblock_attn_kernel<NH>, dim3(grid), dim3(256), LDSB, s, a);
+    const int grid = nwin / WINBLOCK_NW < 256 ? (nwin + WINBLOCK_NW - 1) / WINBLOCK_NW : 256;
+    hipLaunchKernelGGL(winblock_attn_kernel<NH>, dim3(grid), dim3(64 * WINBLOCK_NW), LDSB, s, a);
     LSAM_LAUNCH_CHECK();
     return LSAM_OK;
 }
