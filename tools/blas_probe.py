@@ -2,6 +2,9 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from image_segmentation_amd import _C
+if os.environ.get("LSAM_LIB"):
+    _C.LIB_PATH = os.path.abspath(os.environ["LSAM_LIB"])
 from image_segmentation_amd import ops
 
 def timeit(f, n=30):
