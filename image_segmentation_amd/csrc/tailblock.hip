@@ -896,6 +896,9 @@ __global__ __launch_bounds__(64 * NW, 2) void tailpair_kernel(const TailBlockArg
 #ifndef TAIL_224_NW
 #define TAIL_224_NW 4
 #endif
+#ifndef TAIL_224_MT
+#define TAIL_224_MT 1   // 16-token tiles per wave of the 224-wide kernel
+#endif
 
 // supported widths: exactly 224 (KS 7) and 448 (KS 14), the Hiera-B+ stage-2 / stage-3 widths
 static int tail_variant(int d) {
@@ -1009,7 +1012,7 @@ int launch_tailblock(const TailBlockArgs& a, hipStream_t s) {
 #if TAIL_224_PAIR
         case 0: return launch_tailpair<7, 14, TAIL_224_NW>(a, s);   // wave pairs: a wave keeps 112 channels = 3 1/2 k-steps of fc1's K
 #else
-        case 0: return launch_tail<7, 14, 1, 8, 2>(a, s);    // 8 waves x 16 tokens, four waves per SIMD
+        case 0: return launch_tail<7, 14, TAIL_224_MT, 8, 2>(a, s);    // 8 waves x 16 tokens, two waves per SIMD (254 registers)
 #endif
 #if TAIL_448_PAIR
         case 1: return launch_tailpair<14, 28, 8>(a, s);     // 8 waves, wave pairs share 32 tokens: two waves per SIMD
