@@ -607,8 +607,7 @@ template <int OFF, typename V> __device__ __forceinline__ void g3_rd(unsigned ad
 // and not by 224, so the narrower tile wastes no MFMAs on guard columns).
 template <bool OUTF32, bool POOL, bool NGUARD = false, int NT = 7>
 __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
-    static_assert(!(POOL && NGUARD), "pooled epilogue needs N % 224 == 0");
-    static_assert(NT == 7 || (NT == 6 && !POOL && !NGUARD), "192-wide tiles: plain epilogues, N % 192 == 0");
+    static_assert(NT == 7 || (NT == 6 && !NGUARD), "192-wide tiles: N % 192 == 0");
     using T = bf16;
     constexpr int MT = 4, BM = 256, BN = 32 * NT, WNC = 16 * NT, NW = 8, BK = 64, A_IT = 4;   // WNC: columns per wave
     constexpr int STAGE = 65536;       // 512 rows x 128 B; rows 480..511 only take the padding DMA pieces
@@ -840,7 +839,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
                     const float b = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, true));
                     v[r] = fmaxf(a, b);
                 }
-                if (!(lr & 1)) store4(rowp + 16 * nt, v);
+                if (!(lr & 1) && (!NGUARD || nc + 16 * nt < N)) store4(rowp + 16 * nt, v);   // N % 8 == 0: whole 16-byte groups
             }
         }
     };
@@ -961,7 +960,9 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
 #endif
         if constexpr (POOL) {
             epilogue_pool(t);
-            after = 12;   // 14 stores; counted a little short so that a store the compiler fuses or drops cannot matter
+            // 14 stores (NT = 6: 12), counted a little short so that a store the compiler fuses or drops cannot matter; a
+            // column-guarded last tile issues fewer: wait for everything
+            after = (!NGUARD || (t % tiles_n) * BN + BN <= N) ? (NT == 7 ? 12 : 8) : 0;
         } else {
             epilogue(m0, n0);
             // full tile: 28 (fp32) / 16 (bf16) stores (NT = 6: 24 / 12), counted short; a partial tile issues fewer: wait for everything
@@ -1183,7 +1184,8 @@ template <typename T> static int launch_skinny32(const GemmArgs& a, hipStream_t 
 
 // pooled epilogue: whole TH x TW patches (TW = min(W, 128) a multiple of 32, TH = 256 / TW), 224-wide column tiles
 bool gemm_pool_supported(int H, int W, int N) {
-    if (H <= 0 || W <= 0 || W % 32 != 0 || N % 224 != 0) return false;
+    // N % 224 == 0: full 224-wide tiles; N % 192 == 0: 192-wide ones; any other N >= 144 with N % 8 == 0: column-guarded
+    if (H <= 0 || W <= 0 || W % 32 != 0 || N % 8 != 0 || N < 144) return false;
     const int tw = W < 128 ? W : 128;
     if (tw != 32 && tw != 64 && tw != 128) return false;
     return W % tw == 0 && H % (256 / tw) == 0;
@@ -1252,6 +1254,12 @@ template <typename T> int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
                              (a.flags & ~LSAM_EPI_OUT_F32) == 0 && (a.flags & LSAM_EPI_OUT_F32) && !a.res &&
                              (double)a.M * a.lda * sizeof(T) < 2.0e9 && (double)a.N * a.ldw * sizeof(T) < 2.0e9,
                          LSAM_ERR_UNSUPPORTED, "linear: pooled epilogue not available for this shape");
+            if (GEMM3 && a.N % 224 != 0) {   // Hiera-L widths (288, 576, 1152)
+                LSAM_REQUIRE(a.split_n == 0, LSAM_ERR_UNSUPPORTED, "linear: the split pooled output needs N %% 224 == 0");
+                if (a.N % 192 == 0) return launch_v3<true, true, false, 6>(a, s);
+                return launch_v3<true, true, true>(a, s);
+            }
+            LSAM_REQUIRE(a.N % 224 == 0, LSAM_ERR_UNSUPPORTED, "linear: pooled epilogue needs N %% 224 == 0 in this build");
             if (GEMM3) return launch_v3<true, true>(a, s);
             return launch_v2<T, 2, true, true>(a, s);
         } else {

@@ -478,7 +478,10 @@ def test_patch_embed_direct_rejects_unsupported(ops):
 @pytest.mark.parametrize("n_img,H,Wd,N,K", [(2, 16, 32, 224, 112), (1, 8, 64, 448, 224), (2, 4, 128, 224, 112),
                                             (1, 256, 256, 224, 112), (3, 8, 32, 896, 448),
                                             # more tiles than workgroups: the persistent kernel's tile-to-tile path
-                                            (3, 256, 128, 448, 224), (5, 128, 128, 224, 64)])
+                                            (3, 256, 128, 448, 224), (5, 128, 128, 224, 64),
+                                            # Hiera-L widths: column-guarded 224-wide tiles (288) and 192-wide tiles (576, 1152)
+                                            (2, 64, 64, 288, 144), (1, 32, 128, 576, 288), (2, 16, 32, 1152, 576),
+                                            (1, 8, 32, 152, 40)])
 def test_linear_maxpool2x2(ops, n_img, H, Wd, N, K):
     """shortcut = do_pool(proj(x_norm)) (hieradet.py:139-140, 27-41) with the pool in the GEMM epilogue, against
     F.max_pool2d of the un-pooled fp32 product of the same bf16 operands."""
