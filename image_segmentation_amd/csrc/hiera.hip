@@ -24,6 +24,10 @@ namespace lsam {
 
 constexpr int AUG = 32;       // extra K columns: [q part 16 | v part 16]
 constexpr int PATCH_K = 160;  // 3*7*7 = 147 padded to a multiple of 16
+#ifndef QPOOL_ANY_WIDTH
+#define QPOOL_ANY_WIDTH 1     // pooled queries from the GEMM epilogue at any width the guarded tiles take (0: multiples of 112 only)
+#endif
+static inline bool kv_width_ok(long q) { return QPOOL_ANY_WIDTH ? (2 * q) % 8 == 0 && 2 * q >= 144 : (2 * q) % 224 == 0; }
 #ifndef QKVATTN4
 #define QKVATTN4 1            // 4x4-window blocks: qkv (or k | v) projection inside the attention kernel (0: projection GEMM + attention)
 #endif
@@ -340,7 +344,7 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
         // queries, a quarter of the rows, ever exist: do_pool(q), hieradet.py:69-71) and only k | v are written at
         // full resolution.  The pooled shortcut leaves its un-pooled scratch free for them.
         const bool qpooled = g.pool == 2 && d != q && sizeof(T) == 2 && !g.lora && !grad && (q / g.heads) % 8 == 0 &&
-                             gemm_pool_supported(g.gin, g.gin, q) && (2 * q) % 224 == 0 && Mi >= 1024;
+                             gemm_pool_supported(g.gin, g.gin, q) && kv_width_ok(q) && Mi >= 1024;
         float* qp = qpooled ? at<float>(ws, w.scpre) : nullptr;
         bool q_done = false;
         if (d != q) {  // shortcut = pool(proj(norm1(x)))  (hieradet.py:139-140)
@@ -681,7 +685,7 @@ int lsam_hiera_create(const lsam_hiera_config_t* c, lsam_hiera_t** out) {
         if (c->dtype == LSAM_BF16 && STREAMLIN && !g.lora && !g.fused_attn && !g.fused_qkv4 && g.kq == g.dim) {
             // which rows of the qkv weight the block's projection GEMM multiplies: all of them, or k | v only when the pooled
             // queries come from the pooling epilogue (the plan-time part of forward_t's `qpooled`) and no fused k | v kernel runs
-            const bool kv_only = g.pool == 2 && d != q && (q / g.heads) % 8 == 0 && gemm_pool_supported(g.gin, g.gin, (int)q) && (2 * q) % 224 == 0;
+            const bool kv_only = g.pool == 2 && d != q && (q / g.heads) % 8 == 0 && gemm_pool_supported(g.gin, g.gin, (int)q) && kv_width_ok((long)q);
             const int n0 = kv_only ? (int)q : 0, n = (int)(3 * q) - n0;
             if (!(kv_only && g.fused_kv) && streamlin_supported((int)d, n)) {
                 o.simg = b.take(streamlin_image_bytes((int)d, n));
