@@ -19,7 +19,9 @@ def timeit(f, n=30):
     torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
 
-for M, N, K in ((65536, 1344, 448), (65536, 1792, 448), (65536, 448, 1792), (65536, 448, 448), (262144, 672, 224), (16384, 3584, 896),
+SHAPES_L = ((262144, 1728, 576), (262144, 2304, 576), (262144, 576, 2304), (262144, 576, 576), (1048576, 1152, 288), (1048576, 864, 288),
+            (4194304, 432, 144))
+for M, N, K in SHAPES_L if os.environ.get("BP_L") else ((65536, 1344, 448), (65536, 1792, 448), (65536, 448, 1792), (65536, 448, 448), (262144, 672, 224), (16384, 3584, 896),
                 (16384, 896, 3584), (16384, 2688, 896), (1048576, 448, 112)):
     x = torch.randn(M, K, device="cuda").bfloat16()
     w = (torch.randn(N, K, device="cuda") / K ** 0.5)
