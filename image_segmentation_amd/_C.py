@@ -147,6 +147,11 @@ def lib() -> C.CDLL:
         L.lsam_window_block_pack.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp]
         L.lsam_window_block_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, f, vp]
         L.lsam_mlp_block_pack.argtypes = [vp, vp, vp, vp, i, vp, vp, vp]
+        L.lsam_window_block_attention_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, f, vp]
+        L.lsam_mlp_block_proj_image_bytes.restype = C.c_size_t
+        L.lsam_mlp_block_proj_image_bytes.argtypes = [i]
+        L.lsam_mlp_block_proj_pack.argtypes = [vp, vp, i, vp, vp, vp]
+        L.lsam_mlp_block_fwd_proj.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, vp, vp, vp, i, vp, vp, i, i, f, vp]
         L.lsam_mlp_block_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i, i, f, vp]
         L.lsam_mlp_block_fwd_next_norm.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, vp, vp, i, i, f, vp]
         L.lsam_prof_arm.argtypes = [i]
@@ -194,6 +199,7 @@ EXPORTED = [
     "lsam_neck_topdown_bwd", "lsam_act_bwd", "lsam_mha_bwd", "lsam_upscale2x2_bwd", "lsam_mask_gate_bwd", "lsam_bilinear_upsample_bwd",
     "lsam_batched_outer_ws_floats", "lsam_batched_outer", "lsam_mask_loss_ws_floats", "lsam_mask_loss_sums", "lsam_mask_loss_bwd", "lsam_kv_window_attention_image_bytes", "lsam_kv_window_attention_pack", "lsam_kv_window_attention_fwd",
     "lsam_neck_conv_split_image_bytes", "lsam_neck_conv_pack_split", "lsam_neck_level_fwd_split",
+    "lsam_window_block_attention_fwd", "lsam_mlp_block_proj_image_bytes", "lsam_mlp_block_proj_pack", "lsam_mlp_block_fwd_proj",
     "lsam_qkv_window4_attention_image_bytes", "lsam_qkv_window4_attention_pack", "lsam_qkv_window4_attention_fwd",
     "lsam_stream_linear_image_bytes", "lsam_stream_linear_pack", "lsam_stream_linear_fwd",
     "lsam_outer_reduce_static_max_ws", "lsam_outer_reduce_static_init", "lsam_outer_reduce_static",

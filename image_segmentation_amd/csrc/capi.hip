@@ -234,6 +234,35 @@ int lsam_window_block_fwd(const float* x, float* y, const float* norm1_w, const 
     return launch_winblock_attn(a, nh, static_cast<hipStream_t>(stream));
 }
 
+int lsam_window_block_attention_fwd(const float* x, void* a_out, const float* norm1_w, const float* norm1_b, const void* image,
+                                    const float* bias_table, int N, int H, int W, int nh, int hd, float eps, lsam_stream_t stream) {
+    LSAM_REQUIRE(hd > 0 && a_out, LSAM_ERR_BAD_ARG, "window_block_attention: head_dim must be positive, a_out not null");
+    WinBlockArgs a{x, nullptr, norm1_w, norm1_b, image, bias_table, N, H, W, hd, eps, (1.0f / sqrtf((float)hd)) * 1.4426950408889634f};
+    a.a_out = a_out;
+    return launch_winblock_attn(a, nh, static_cast<hipStream_t>(stream));
+}
+size_t lsam_mlp_block_proj_image_bytes(int d) { return mlpblock_proj_supported(d) ? mlpblock_proj_image_bytes(d) : 0; }
+int lsam_mlp_block_proj_pack(const float* proj_w, const float* proj_b, int d, void* proj_image, float* proj_bias, lsam_stream_t stream) {
+    return launch_pack_mlpblock_proj(proj_w, proj_b, d, proj_image, proj_bias, static_cast<hipStream_t>(stream));
+}
+int lsam_mlp_block_fwd_proj(const float* x, const void* a_in, int lda, float* y, const float* norm2_w, const float* norm2_b,
+                            const void* image, const float* bias_table, const void* proj_image, const float* proj_bias,
+                            void* xn_next, int ldn, const float* next_norm_w, const float* next_norm_b, int M, int d, float eps,
+                            lsam_stream_t stream) {
+    LSAM_REQUIRE(mlpblock_proj_supported(d), LSAM_ERR_UNSUPPORTED, "mlp_block_fwd_proj: width %d not supported", d);
+    LSAM_REQUIRE(a_in && proj_image && proj_bias, LSAM_ERR_BAD_ARG, "mlp_block_fwd_proj: null argument");
+    MlpBlockArgs a{x, y, norm2_w, norm2_b, image, bias_table, M, d, mlpblock_chunks(d), eps};
+    a.xn_next = xn_next;
+    a.ldn = ldn;
+    a.gamma_n = next_norm_w;
+    a.beta_n = next_norm_b;
+    a.a = a_in;
+    a.lda = lda;
+    a.pimg = proj_image;
+    a.pbias = proj_bias;
+    return launch_mlpblock(a, static_cast<hipStream_t>(stream));
+}
+
 size_t lsam_mlp_block_image_bytes(int d) { return mlpblock_supported(d) ? mlpblock_image_bytes(d) : 0; }
 size_t lsam_mlp_block_bias_floats(int d) { return mlpblock_supported(d) ? mlpblock_bias_floats(d) : 0; }
 int lsam_mlp_block_pack(const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b, int d,

@@ -28,6 +28,9 @@ constexpr int PATCH_K = 160;  // 3*7*7 = 147 padded to a multiple of 16
 #define QPOOL_ANY_WIDTH 1     // pooled queries from the GEMM epilogue at any width the guarded tiles take (0: multiples of 112 only)
 #endif
 static inline bool kv_width_ok(long q) { return QPOOL_ANY_WIDTH ? (2 * q) % 8 == 0 && 2 * q >= 144 : (2 * q) % 224 == 0; }
+#ifndef SPLIT_PROJ
+#define SPLIT_PROJ 1          // stage-1 blocks: proj + residual in the MLP kernel instead of the attention kernel (0: as before)
+#endif
 #ifndef QKVATTN4
 #define QKVATTN4 1            // 4x4-window blocks: qkv (or k | v) projection inside the attention kernel (0: projection GEMM + attention)
 #endif
@@ -45,6 +48,7 @@ struct BlockGeom {
     bool fused_attn;  // bf16 only: LN1 + qkv + window attention + proj + residual in one kernel (winblock.hip)
     bool fused_mlp;   // bf16 only: LN2 + fc1 + GELU + fc2 + residual in one kernel (mlpblock.hip)
     bool fused_tail;  // bf16 only: proj + residual + LN2 + MLP + residual (+ next block's LN1) in one kernel (tailblock.hip)
+    bool split_proj;  // fused_attn + fused_mlp: the attention kernel stops at its output rows, proj + residual open the MLP kernel
     bool fused_qkv4;  // bf16 only: qkv (k | v for a q-pool block) projection + 4x4-window attention in one kernel (qkvattn.hip)
     bool fused_kv;    // bf16 only: k | v projection + 8x8-window attention of a q-pool stage-entry block in one kernel (kvattn.hip)
 };
@@ -54,6 +58,7 @@ struct BlockOff {
     size_t bqkvT;  // qkv bias in T (pad-token k/v source of the LDS-DMA attention kernel)
     size_t wimg, wbias;  // fused window-block weight image + padded biases (winblock.hip), if g.fused_attn
     size_t mimg, mbias;  // fused MLP weight image + fc2 bias (mlpblock.hip), if g.fused_mlp
+    size_t mpimg, mpbias; // the attention projection as a chunk of that kernel's weight stream + its bias, if g.split_proj
     size_t timg, tvec;   // fused tail weight stream + packed vectors (tailblock.hip), if g.fused_tail
     size_t kvimg;        // k | v weight image of the fused projection + attention kernel (kvattn.hip), if g.fused_kv
     size_t qaimg;        // weight image of the fused projection + 4x4-window attention kernel (qkvattn.hip), if g.fused_qkv4
@@ -248,6 +253,8 @@ static int pack_t(lsam_hiera* h, const lsam_block_params_t* bp, const float* pat
         if (g.fused_mlp)
             LSAM_TRY(launch_pack_mlpblock(p.fc1_w, p.fc1_b, p.fc2_w, p.fc2_b, q, at<char>(arena, o.mimg),
                                           at<float>(arena, o.mbias), s));
+        if (g.split_proj)
+            LSAM_TRY(launch_pack_mlpblock_proj(p.attn_proj_w, p.attn_proj_b, q, at<char>(arena, o.mpimg), at<float>(arena, o.mpbias), s));
         if (g.fused_tail)
             LSAM_TRY(launch_pack_tailblock(p.attn_proj_w, p.attn_proj_b, p.norm2_w, p.norm2_b, p.fc1_w, p.fc1_b, p.fc2_w,
                                            p.fc2_b, q, at<char>(arena, o.timg), at<float>(arena, o.tvec), s));
@@ -323,6 +330,9 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
             WinBlockArgs wa{x, x, at<float>(arena, o.ln1w), at<float>(arena, o.ln1b), at<char>(arena, o.wimg),
                             at<float>(arena, o.wbias), N, g.gin, g.gin, q / g.heads, 1e-6f,
                             (1.0f / sqrtf((float)(q / g.heads))) * 1.4426950408889634f};
+            if constexpr (sizeof(T) == 2) {
+                if (g.split_proj) wa.a_out = at<T>(ws, w.a);   // attention rows only; proj + residual open the MLP kernel below
+            }
             LSAM_TRY(launch_winblock_attn(wa, g.heads, s));
             y = x;
         } else {
@@ -442,6 +452,12 @@ static int forward_t(lsam_hiera* h, const float* img, int N, float* const* stage
                             at<float>(arena, o.mbias), Mo, q, mlpblock_chunks(q), 1e-6f};
             // the next block's norm1 from the same registers when that block starts with a plain LayerNorm
             const bool next_ln = !last && !h->blk[i + 1].fused_attn && !h->blk[i + 1].lora && h->blk[i + 1].dim == q;
+            if (g.split_proj) {
+                ma.a = at<T>(ws, w.a);
+                ma.lda = q;
+                ma.pimg = at<char>(arena, o.mpimg);
+                ma.pbias = at<float>(arena, o.mpbias);
+            }
             if (next_ln) {
                 ma.xn_next = at<T>(ws, w.xn);
                 ma.ldn = h->blk[i + 1].kq;
@@ -601,6 +617,7 @@ int lsam_hiera_create(const lsam_hiera_config_t* c, lsam_hiera_t** out) {
                        winblock_supported(g.gin, g.gin, g.ws, g.pool, g.heads, g.dout / g.heads, g.dim, g.dout);
         g.fused_tail = c->dtype == LSAM_BF16 && !g.lora && !g.fused_attn && tailblock_supported(g.dout);
         g.fused_mlp = c->dtype == LSAM_BF16 && !g.lora && !g.fused_tail && mlpblock_supported(g.dout);
+        g.split_proj = SPLIT_PROJ && g.fused_attn && g.fused_mlp && mlpblock_proj_supported(g.dout);
         // (the conditions under which forward_t takes the pooled-query path, plus the kernel's own)
         g.fused_kv = c->dtype == LSAM_BF16 && !g.lora && g.dim != g.dout && g.dout % g.heads == 0 &&
                      kvattn_supported(g.gin, g.gin, g.ws, g.pool, g.heads, g.dout / g.heads, g.dim, g.dout) &&
@@ -675,6 +692,10 @@ int lsam_hiera_create(const lsam_hiera_config_t* c, lsam_hiera_t** out) {
         if (g.fused_mlp) {
             o.mimg = b.take(mlpblock_image_bytes(g.dout));
             o.mbias = b.take(mlpblock_bias_floats(g.dout) * 4);
+            if (g.split_proj) {
+                o.mpimg = b.take(mlpblock_proj_image_bytes(g.dout));
+                o.mpbias = b.take(16 * 14 * 4);
+            }
         }
         if (g.fused_tail) {
             o.timg = b.take(tailblock_image_bytes(g.dout));

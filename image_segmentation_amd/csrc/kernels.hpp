@@ -164,6 +164,7 @@ struct WinBlockArgs {
     const float* bias_p;  // padded qkv + proj biases
     int N, H, W, hd;
     float eps, c_log2;    // LN epsilon; softmax scale * log2(e)
+    void* a_out = nullptr;   // attention-only form: the attention output rows, bf16 [N*H*W][D], instead of y (no proj, no residual)
 };
 size_t winblock_image_bytes(int nh);
 size_t winblock_bias_floats(int nh);
@@ -183,8 +184,14 @@ struct MlpBlockArgs {
     float eps;
     // optional: LayerNorm of the block's OUTPUT with the next block's norm1 parameters, T = bf16 [M][ldn]
     void* xn_next = nullptr; int ldn = 0; const float* gamma_n = nullptr; const float* beta_n = nullptr;
+    // optional: the attention projection in front (hieradet.py:79,163): x + proj(a) takes the place of x.  a bf16 [M][lda] (the
+    // attention output of launch_winblock_attn's attention-only form), pimg / pbias from launch_pack_mlpblock_proj
+    const void* a = nullptr; int lda = 0; const void* pimg = nullptr; const float* pbias = nullptr;
 };
 bool mlpblock_supported(int d);
+bool mlpblock_proj_supported(int d);
+size_t mlpblock_proj_image_bytes(int d);
+int launch_pack_mlpblock_proj(const float* wproj, const float* bproj, int d, void* pimg, float* pbias, hipStream_t s);
 int mlpblock_chunks(int d);
 size_t mlpblock_image_bytes(int d);
 size_t mlpblock_bias_floats(int d);

@@ -20,6 +20,9 @@ namespace lsam {
 #ifndef MLP_ABL
 #define MLP_ABL 0
 #endif
+#ifndef MLP_PROJ_LDS
+#define MLP_PROJ_LDS 1   // PROJ: W_proj as one more chunk of the LDS stream (1) or read from L2 as fragments (0: 595 us against 524, 36 spills)
+#endif
 typedef __attribute__((address_space(3))) void* mlp_lds_p;
 typedef const __attribute__((address_space(1))) void* mlp_gbl_p;
 typedef __attribute__((address_space(3))) const char* mlp_lds_cp;
@@ -91,8 +94,31 @@ __global__ void pack_mlpblock_kernel(const float* __restrict__ w1, const float* 
         bias_p[i] = i < d ? b2[i] : 0.f;
 }
 
-template <int KS, int NTO, int MT, int NW>
+// PROJ: the attention projection in front -- y = x + b_proj + a . W_proj^T takes the place of x (hieradet.py:79,163).  W_proj is
+// one more chunk of the weight stream (fragment order, NTO x KS KiB: fits a chunk buffer for the 64- and 112-wide variants),
+// consumed between the x loads and LayerNorm 2; the stage-1 attention kernel then stops at its attention output (winblock.hip,
+// ATTN_ONLY), whose proj + residual phase cost it a third of its time at one wave per SIMD, while this kernel is VALU-bound.
+// W_proj as one chunk: fragment (nt, ks) at (nt KS + ks) KiB, lane (g, lr) = row 16 nt + lr, k = 32 ks + 8 g + j (natural K order:
+// the attention rows are read as they lie in memory); the rest of the chunk is zero.  pbias: b_proj padded to 16 NTO.
+template <int KS, int NTO>
+__global__ void pack_mlpproj_kernel(const float* __restrict__ wproj, const float* __restrict__ bproj, int d, char* __restrict__ img,
+                                    float* __restrict__ pbias) {
+    constexpr int CB = MlpImg<KS, NTO>::CHUNK_B;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < CB / 2; i += gridDim.x * blockDim.x) {
+        const int f = i >> 9, lane = (i & 511) >> 3, j = i & 7;
+        float v = 0.f;
+        if (f < NTO * KS) {
+            const int nt = f / KS, ks = f % KS, row = 16 * nt + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + j;
+            if (row < d && k < d) v = wproj[(size_t)row * d + k];
+        }
+        reinterpret_cast<bf16*>(img)[i] = (bf16)v;
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 16 * NTO; i += gridDim.x * blockDim.x) pbias[i] = i < d ? bproj[i] : 0.f;
+}
+
+template <int KS, int NTO, int MT, int NW, bool PROJ = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlpblock_kernel(const MlpBlockArgs p) {
+    static_assert(!PROJ || NTO * KS * 1024 <= MlpImg<KS, NTO>::CHUNK_B, "the proj fragments must fit a chunk buffer");
     using I = MlpImg<KS, NTO>;
     constexpr int CB = I::CHUNK_B, TPW = 16 * MT, TPG = TPW * NW;
     constexpr int NDMA = CB / 1024;   // 1 KiB DMA wave-instructions per chunk
@@ -112,12 +138,40 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlpblock_kernel(cons
 #endif
         const char* src = img + (size_t)c * CB;
         char* dst = smem + buf * CB;
+        // PROJ: the lane's byte offset is rebuilt here from an opaque lane id -- kept live across the token loop the per-piece
+        // source addresses are spilled, and a scratch reload waits for vmcnt(0), i.e. for the DMA piece issued just before it
+        unsigned lo = 0;
+        if constexpr (PROJ) {
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
+            lo *= 16;
+        }
+#pragma unroll
+        for (int i = 0; i < (NDMA + NW - 1) / NW; ++i) {
+            const int j = wave + NW * i;
+            if (j < NDMA) {
+                if constexpr (PROJ) __builtin_amdgcn_global_load_lds((mlp_gbl_p)(src + j * 1024 + lo), (mlp_lds_p)(dst + j * 1024), 16, 0, 0);
+                else __builtin_amdgcn_global_load_lds((mlp_gbl_p)(src + j * 1024 + lane * 16), (mlp_lds_p)(dst + j * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto issue_proj = [&](int buf) {   // the W_proj chunk (PROJ): same size, its own image
+        const char* src = static_cast<const char*>(p.pimg);
+        char* dst = smem + buf * CB;
+        unsigned lo;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
+        lo *= 16;
 #pragma unroll
         for (int i = 0; i < (NDMA + NW - 1) / NW; ++i) {
             const int j = wave + NW * i;
             if (j < NDMA)
-                __builtin_amdgcn_global_load_lds((mlp_gbl_p)(src + j * 1024 + lane * 16), (mlp_lds_p)(dst + j * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((mlp_gbl_p)(src + j * 1024 + lo), (mlp_lds_p)(dst + j * 1024), 16, 0, 0);
         }
+    };
+    // chunk after MLP chunk c in stream order: c + 1, or the first chunk of the next token group (W_proj under PROJ)
+    auto issue_next = [&](int c, int buf) {
+        if (c + 1 < nch) issue(c + 1, buf);
+        else if constexpr (PROJ && MLP_PROJ_LDS) issue_proj(buf);
+        else issue(0, buf);
     };
     auto wfrag = [&](const char* base, int row, int c) -> bf16x8 {
         return *reinterpret_cast<const bf16x8*>(base + row * 128 + ((c ^ (row & 7)) << 4));
@@ -125,7 +179,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlpblock_kernel(cons
 
     const int ngroups = (M + TPG - 1) / TPG;
     int buf = 0;
-    issue(0, 0);
+    if constexpr (PROJ && MLP_PROJ_LDS) issue_proj(0);
+    else issue(0, 0);
 #pragma unroll 1
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int m0 = grp * TPG + wave * TPW;
@@ -136,19 +191,91 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlpblock_kernel(cons
         // Rows past M are clamped and never stored.
         bf16x8 xn[MT][KS];
         f32x4 acc2[MT][NTO];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = min(m0 + mt * 16 + lr, M - 1);
+            const float* row = p.x + (size_t)m * d;
+#pragma unroll
+            for (int nt = 0; nt < NTO; ++nt) {
+                const int c0 = 16 * nt + 4 * g;
+                acc2[mt][nt] = c0 < d ? load4(row + c0) : zero4;
+            }
+        }
+        if constexpr (PROJ) {
+            // ---- y = x + b_proj + a . W_proj^T: the token's attention rows are the B operand as they lie in memory (lane:
+            //      token lr, channels 32 ks + 8 g ..), the W_proj tile the A operand; the result lands in acc2's layout ----------
+            bf16x8 af[MT][KS];
+            const bf16* __restrict__ ap = static_cast<const bf16*>(p.a);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const bf16* row = ap + (size_t)min(m0 + mt * 16 + lr, M - 1) * p.lda;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int k0 = 32 * ks + 8 * g;
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (k0 < d) v = *reinterpret_cast<const uint4*>(row + k0);
+                    af[mt][ks] = __builtin_bit_cast(bf16x8, v);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTO; ++nt) {
+                const int c0 = 16 * nt + 4 * g;
+                if (c0 < d) {
+                    const f32x4 b = load4(p.pbias + c0);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc2[mt][nt] += b;
+                }
+            }
+            if constexpr (MLP_PROJ_LDS) {
+                lds_dma_wait_barrier();   // the W_proj chunk landed; every wave is done with the other buffer
+                // (asm reads, ordered by hand, for the reason given at mlp_rd; fragment (nt, ks) at (nt KS + ks) KiB + lane * 16)
+                const unsigned pb = (unsigned)(size_t)(mlp_lds_cp)(smem) + buf * CB + lane * 16;
+                // one k-step's NTO fragments are read while the previous k-step multiplies
+                bf16x8 pw[2][NTO];
+                mlp_static_for<0, NTO>([&](auto nt_) { mlp_rd<(decltype(nt_)::value * KS) * 1024>(pb, pw[0][decltype(nt_)::value]); });
+                issue(0, buf ^ 1);   // the first MLP chunk
+                mlp_static_for<0, KS>([&](auto ks_) {
+                    constexpr int ks = decltype(ks_)::value;
+                    mlp_lds_wait();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (ks + 1 < KS)
+                        mlp_static_for<0, NTO>([&](auto nt_) { mlp_rd<(decltype(nt_)::value * KS + ks + 1) * 1024>(pb, pw[(ks + 1) & 1][decltype(nt_)::value]); });
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int nt = 0; nt < NTO; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) mma16(pw[ks & 1][nt], af[mt][ks], acc2[mt][nt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                buf ^= 1;
+            } else {
+                // W_proj fragments straight from L2 (28 KiB, hot: every token group of every workgroup reads them), one k-step
+                // ahead of the MFMAs that use them: no extra step in the chunk stream, no extra barrier (as one more chunk of
+                // the LDS stream -- MLP_PROJ_LDS, the default -- the kernel takes 524 us against 442 without the projection; this form 595)
+                const bf16x8* __restrict__ pf = reinterpret_cast<const bf16x8*>(p.pimg) + lane;
+                bf16x8 pw[2][NTO];
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt) pw[0][nt] = pf[(nt * KS) * 64];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    if (ks + 1 < KS) {
+#pragma unroll
+                        for (int nt = 0; nt < NTO; ++nt) pw[(ks + 1) & 1][nt] = pf[(nt * KS + ks + 1) * 64];
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NTO; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) mma16(pw[ks & 1][nt], af[mt][ks], acc2[mt][nt]);
+                }
+            }
+        }
         {
             float mean[MT], rstd[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int m = min(m0 + mt * 16 + lr, M - 1);
-                const float* row = p.x + (size_t)m * d;
                 float s = 0.f;
 #pragma unroll
-                for (int nt = 0; nt < NTO; ++nt) {
-                    const int c0 = 16 * nt + 4 * g;
-                    acc2[mt][nt] = c0 < d ? load4(row + c0) : zero4;
-                    s += (acc2[mt][nt][0] + acc2[mt][nt][1]) + (acc2[mt][nt][2] + acc2[mt][nt][3]);
-                }
+                for (int nt = 0; nt < NTO; ++nt) s += (acc2[mt][nt][0] + acc2[mt][nt][1]) + (acc2[mt][nt][2] + acc2[mt][nt][3]);
                 s += __shfl_xor(s, 16, 64);
                 s += __shfl_xor(s, 32, 64);
                 mean[mt] = s / (float)d;
@@ -196,7 +323,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlpblock_kernel(cons
             lds_dma_wait_barrier();   // chunk c landed; every wave is done with the other buffer
             // next chunk in stream order (wraps to chunk 0 of the next token group)
             const bool more = c + 1 < nch || grp + (int)gridDim.x < ngroups;
-            const int next_c = c + 1 < nch ? c + 1 : 0;
             if constexpr (KS == 4 && NTO == 7) {
                 // the 112-wide stage: hand-ordered LDS reads, so that the DMA of the next chunk really
                 // runs under this chunk's MFMAs and GELU.  Fragment (row tile nt, 16-byte column c) sits at
@@ -212,7 +338,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlpblock_kernel(cons
                     constexpr int i = decltype(i_)::value, ks = i >> 2, nt = i & 3;
                     mlp_rd<(ks >> 1) * 8192 + nt * 2048>((ks & 1) ? a1 : a0, wa[i]);
                 });
-                if (more) issue(next_c, buf ^ 1);
+                if (more) issue_next(c, buf ^ 1);
                 mlp_lds_wait();
                 mlp_static_for<0, 8>([&](auto i_) {   // k-steps 2, 3
                     constexpr int i = decltype(i_)::value, ks = 2 + (i >> 2), nt = i & 3;
@@ -262,7 +388,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlpblock_kernel(cons
                 buf ^= 1;
                 continue;
             }
-            if (more) issue(next_c, buf ^ 1);
+            if (more) issue_next(c, buf ^ 1);
 #if MLP_ABL & 2
             buf ^= 1;
             continue;
@@ -398,6 +524,19 @@ static int mlp_variant(int d) {
     return -1;
 }
 bool mlpblock_supported(int d) { return mlp_variant(d) >= 0; }
+// the projection in front: where the W_proj fragments fit one chunk buffer (the 64- and 112-wide variants)
+bool mlpblock_proj_supported(int d) { return mlp_variant(d) == 0 || mlp_variant(d) == 1; }
+size_t mlpblock_proj_image_bytes(int d) {
+    return mlp_variant(d) == 0 ? (size_t)MlpImg<2, 4>::CHUNK_B : mlp_variant(d) == 1 ? (size_t)MlpImg<4, 7>::CHUNK_B : 0;
+}
+int launch_pack_mlpblock_proj(const float* wproj, const float* bproj, int d, void* pimg, float* pbias, hipStream_t s) {
+    LSAM_REQUIRE(wproj && bproj && pimg && pbias, LSAM_ERR_BAD_ARG, "pack_mlpblock_proj: null argument");
+    LSAM_REQUIRE(mlpblock_proj_supported(d), LSAM_ERR_UNSUPPORTED, "pack_mlpblock_proj: width %d", d);
+    if (mlp_variant(d) == 0) hipLaunchKernelGGL((pack_mlpproj_kernel<2, 4>), dim3(32), dim3(256), 0, s, wproj, bproj, d, static_cast<char*>(pimg), pbias);
+    else hipLaunchKernelGGL((pack_mlpproj_kernel<4, 7>), dim3(32), dim3(256), 0, s, wproj, bproj, d, static_cast<char*>(pimg), pbias);
+    LSAM_LAUNCH_CHECK();
+    return LSAM_OK;
+}
 int mlpblock_chunks(int d) { return (4 * d + 63) / 64; }
 size_t mlpblock_image_bytes(int d) {
     const int nch = mlpblock_chunks(d);
@@ -425,9 +564,9 @@ int launch_pack_mlpblock(const float* w1, const float* b1, const float* w2, cons
     return LSAM_OK;
 }
 
-template <int KS, int NTO, int MT, int NW> static int launch_mlp(const MlpBlockArgs& a, hipStream_t s) {
+template <int KS, int NTO, int MT, int NW, bool PROJ = false> static int launch_mlp(const MlpBlockArgs& a, hipStream_t s) {
     constexpr int LDSB = 2 * MlpImg<KS, NTO>::CHUNK_B;
-    auto kern = mlpblock_kernel<KS, NTO, MT, NW>;
+    auto kern = mlpblock_kernel<KS, NTO, MT, NW, PROJ>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         LSAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
@@ -452,10 +591,14 @@ int launch_mlpblock(const MlpBlockArgs& a, hipStream_t s) {
         LSAM_REQUIRE(a.gamma_n && a.beta_n && a.ldn >= a.d && a.ldn % 4 == 0 && aligned16(a.gamma_n) && aligned16(a.beta_n) &&
                          (reinterpret_cast<uintptr_t>(a.xn_next) & 15) == 0,
                      LSAM_ERR_BAD_ARG, "mlpblock: next-LayerNorm output needs gamma, beta, 16-byte alignment and ldn %% 4 == 0");
-    ProfScope ps(s, (double)a.M * a.d * (8.0 + (a.xn_next ? 2.0 : 0.0)), PROF_MLPBLOCK, a.M, a.d, 0);   // x in + y out (+ bf16 next LN)
+    if (a.a)
+        LSAM_REQUIRE(mlpblock_proj_supported(a.d) && a.pimg && a.pbias && a.lda >= a.d && a.lda % 8 == 0 && aligned16(a.a) &&
+                         aligned16(a.pimg) && aligned16(a.pbias),
+                     LSAM_ERR_BAD_ARG, "mlpblock: the projection in front needs width <= 112, its packed image and bias, lda %% 8 == 0");
+    ProfScope ps(s, (double)a.M * a.d * (8.0 + (a.xn_next ? 2.0 : 0.0) + (a.a ? 2.0 : 0.0)), PROF_MLPBLOCK, a.M, a.d, 0);   // x in + y out (+ bf16 next LN, + bf16 a)
     switch (mlp_variant(a.d)) {
-        case 0: return launch_mlp<2, 4, 2, 4>(a, s);
-        case 1: return launch_mlp<4, 7, 2, 4>(a, s);
+        case 0: return a.a ? launch_mlp<2, 4, 2, 4, true>(a, s) : launch_mlp<2, 4, 2, 4>(a, s);
+        case 1: return a.a ? launch_mlp<4, 7, 2, 4, true>(a, s) : launch_mlp<4, 7, 2, 4>(a, s);
         case 2: return launch_mlp<7, 14, 2, 8>(a, s);
         case 3: return launch_mlp<5, 9, 2, 8>(a, s);
     }

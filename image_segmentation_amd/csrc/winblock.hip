@@ -78,7 +78,7 @@ __global__ void pack_winblock_kernel(const float* __restrict__ wqkv, const float
 #ifndef WINBLOCK_NW
 #define WINBLOCK_NW 4   // waves per workgroup (one workgroup per CU: the weight image fills the LDS)
 #endif
-template <int NH>
+template <int NH, bool ATTN_ONLY>
 __global__ __launch_bounds__(64 * WINBLOCK_NW, 1) void winblock_attn_kernel(const WinBlockArgs p) {
     constexpr int NW = WINBLOCK_NW;
     using I = WinImg<NH>;
@@ -302,18 +302,28 @@ __global__ __launch_bounds__(64 * WINBLOCK_NW, 1) void winblock_attn_kernel(cons
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vtf[0][dt], pf[0], zero4, 0, 0, 0);
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vtf[1][dt], pf[1], o[dt], 0, 0, 0);
                 }
+                if constexpr (ATTN_ONLY) {
+                    // the attention output rows as they are (lane: query lr, channels 16 dt + 4 g + r); proj + residual are
+                    // taken by the MLP kernel behind this one (mlpblock.hip, PROJ), which is VALU-bound and has the MFMA room
+                    bf16* arow = static_cast<bf16*>(p.a_out) + tok_row(it * 16 + lr) * D + h * hd;
 #pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2) {
-                    bf16x8 f;
+                    for (int dt = 0; dt < 4; ++dt)
+                        if (16 * dt + 4 * g < hd) store4(arow + 16 * dt + 4 * g, o[dt] * inv);
+                } else {
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        bf16x8 f;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) f[4 * t + r] = (bf16)(o[2 * k2 + t][r] * inv);
-                    of[h][it][k2] = f;
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) f[4 * t + r] = (bf16)(o[2 * k2 + t][r] * inv);
+                        of[h][it][k2] = f;
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if constexpr (ATTN_ONLY) continue;
 
         // ---- proj + residual: x1 = x + o . Wproj^T + b  (lane = token, 4 consecutive channels) -------
 #pragma unroll
@@ -385,31 +395,32 @@ int launch_pack_winblock(const float* wqkv, const float* bqkv, const float* wpro
     return LSAM_OK;
 }
 
-template <int NH> static int launch_wb(const WinBlockArgs& a, hipStream_t s) {
+template <int NH, bool ATTN_ONLY> static int launch_wb(const WinBlockArgs& a, hipStream_t s) {
     constexpr int LDSB = WinImg<NH>::BYTES;
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        LSAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(winblock_attn_kernel<NH>),
+        LSAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(winblock_attn_kernel<NH, ATTN_ONLY>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
         attr_set = true;
     }
     const int nwin = a.N * (a.H / 8) * (a.W / 8);
     const int grid = nwin / WINBLOCK_NW < 256 ? (nwin + WINBLOCK_NW - 1) / WINBLOCK_NW : 256;
-    hipLaunchKernelGGL(winblock_attn_kernel<NH>, dim3(grid), dim3(64 * WINBLOCK_NW), LDSB, s, a);
+    hipLaunchKernelGGL((winblock_attn_kernel<NH, ATTN_ONLY>), dim3(grid), dim3(64 * WINBLOCK_NW), LDSB, s, a);
     LSAM_LAUNCH_CHECK();
     return LSAM_OK;
 }
 
 int launch_winblock_attn(const WinBlockArgs& a, int nh, hipStream_t s) {
-    LSAM_REQUIRE(a.x && a.y && a.gamma && a.beta && a.img && a.bias_p, LSAM_ERR_BAD_ARG, "winblock: null argument");
+    LSAM_REQUIRE(a.x && (a.y || a.a_out) && a.gamma && a.beta && a.img && a.bias_p, LSAM_ERR_BAD_ARG, "winblock: null argument");
     LSAM_REQUIRE(a.N > 0 && a.H > 0 && a.W > 0 && a.H % 8 == 0 && a.W % 8 == 0, LSAM_ERR_UNSUPPORTED,
                  "winblock: grid %dx%d is not a multiple of the 8x8 window", a.H, a.W);
     LSAM_REQUIRE((nh == 1 || nh == 2) && a.hd % 8 == 0 && a.hd >= 16 && a.hd <= 64, LSAM_ERR_UNSUPPORTED,
                  "winblock: heads %d x %d", nh, a.hd);
-    LSAM_REQUIRE(aligned16(a.x) && aligned16(a.y) && aligned16(a.img) && aligned16(a.gamma) && aligned16(a.beta) &&
+    LSAM_REQUIRE(aligned16(a.x) && aligned16(a.y) && aligned16(a.a_out) && aligned16(a.img) && aligned16(a.gamma) && aligned16(a.beta) &&
                      aligned16(a.bias_p), LSAM_ERR_BAD_ARG, "winblock: pointers must be 16-byte aligned");
-    ProfScope ps(s, (double)a.N * a.H * a.W * nh * a.hd * 8.0, PROF_WINBLOCK, a.N * a.H * a.W, nh * a.hd, 0);   // x in + y out, fp32
-    return nh == 1 ? launch_wb<1>(a, s) : launch_wb<2>(a, s);
+    ProfScope ps(s, (double)a.N * a.H * a.W * nh * a.hd * (a.a_out ? 6.0 : 8.0), PROF_WINBLOCK, a.N * a.H * a.W, nh * a.hd, 0);   // x in (fp32) + y out (fp32) or a out (bf16)
+    if (a.a_out) return nh == 1 ? launch_wb<1, true>(a, s) : launch_wb<2, true>(a, s);
+    return nh == 1 ? launch_wb<1, false>(a, s) : launch_wb<2, false>(a, s);
 }
 
 }  // namespace lsam

@@ -293,6 +293,50 @@ def mlp_block_fwd_next_norm(x, norm2_w, norm2_b, img, bias, next_norm_w, next_no
     return y, xn
 
 
+def window_block_attention_fwd(x, norm1_w, norm1_b, img, bias, nh: int, eps: float = 1e-6):
+    """a = attn(qkv(LN1(x))) as bf16 [N,H,W,d]: the attention-only form of window_block_fwd (see lsam_window_block_attention_fwd)."""
+    _need_gpu(x, norm1_w, norm1_b, img, bias)
+    norm1_w, norm1_b = _f32c(norm1_w), _f32c(norm1_b)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    N, H, W, d = x.shape
+    a = torch.empty(N, H, W, d, dtype=torch.bfloat16, device=x.device)
+    check(lib().lsam_window_block_attention_fwd(ptr(x), ptr(a), ptr(norm1_w), ptr(norm1_b), ptr(img), ptr(bias), N, H, W, nh,
+                                                d // nh, eps, stream()))
+    return a
+
+
+def mlp_block_proj_pack(proj_w, proj_b):
+    """attn.proj as one chunk of the MLP block kernel's weight stream (see lsam_mlp_block_fwd_proj): (image, bias)."""
+    _need_gpu(proj_w, proj_b)
+    d = proj_w.shape[0]
+    nbytes = lib().lsam_mlp_block_proj_image_bytes(d)
+    if nbytes == 0:
+        raise _C.LsamError(f"fused MLP block with the projection in front: width {d} not supported")
+    img = torch.empty(nbytes, dtype=torch.uint8, device=proj_w.device)
+    pb = torch.empty(16 * 14, dtype=torch.float32, device=proj_w.device)
+    check(lib().lsam_mlp_block_proj_pack(ptr(_f32c(proj_w)), ptr(_f32c(proj_b)), d, ptr(img), ptr(pb), stream()))
+    return img, pb
+
+
+def mlp_block_fwd_proj(x, a, norm2_w, norm2_b, img, bias, pimg, pbias, next_norm=None, eps: float = 1e-6):
+    """y1 = x + proj(a); y = y1 + fc2(GELU(fc1(LN2(y1)))) (and LayerNorm_next(y) as bf16 with next_norm = (w, b)):
+    x fp32 [M, d], a bf16 [M, d] (see lsam_mlp_block_fwd_proj)."""
+    _need_gpu(x, a, norm2_w, norm2_b, img, bias, pimg, pbias)
+    norm2_w, norm2_b = _f32c(norm2_w), _f32c(norm2_b)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+    assert a.dtype == torch.bfloat16 and a.is_contiguous() and a.shape == x.shape
+    M, d = x.shape
+    y = torch.empty_like(x)
+    xn, nw, nb = None, None, None
+    if next_norm is not None:
+        nw, nb = _f32c(next_norm[0]), _f32c(next_norm[1])
+        xn = torch.empty(M, d, dtype=torch.bfloat16, device=x.device)
+    check(lib().lsam_mlp_block_fwd_proj(ptr(x), ptr(a), d, ptr(y), ptr(norm2_w), ptr(norm2_b), ptr(img), ptr(bias), ptr(pimg),
+                                        ptr(pbias), ptr(xn) if xn is not None else None, d, ptr(nw) if nw is not None else None,
+                                        ptr(nb) if nb is not None else None, M, d, eps, stream()))
+    return (y, xn) if next_norm is not None else y
+
+
 def lateral_conv_supported(in_channels: int, out_channels: int) -> bool:
     return lib().lsam_lateral_conv_image_bytes(in_channels, out_channels) > 0
 

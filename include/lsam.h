@@ -371,6 +371,24 @@ int lsam_mlp_block_fwd_next_norm(const float* x, float* y, const float* norm2_w,
                                  const float* bias_table, void* xn_next, int ldn, const float* next_norm_w,
                                  const float* next_norm_b, int M, int d, float eps, lsam_stream_t stream);
 
+/* The same two kernels with the attention projection moved from the first into the second (what the plan runs for the
+ * stage-1 blocks: at one wave per SIMD the attention kernel spends a third of its time in proj + residual, the MLP kernel is
+ * VALU-bound and has the matrix pipe to spare):
+ *   lsam_window_block_attention_fwd:  a = attn(qkv(LayerNorm1(x)))  -- the attention output rows (hieradet.py:59-77 inside
+ *       window_partition / unpartition), bf16 [N*H*W][nh*hd]; same image and bias table as lsam_window_block_fwd;
+ *   lsam_mlp_block_fwd_proj:  y1 = x + proj(a) (hieradet.py:79,163), y = y1 + fc2(GELU(fc1(LayerNorm2(y1)))) (:165), and
+ *       optionally xn_next as in lsam_mlp_block_fwd_next_norm (NULL: not written).  a bf16 [M][lda], lda % 8 == 0.
+ *       proj_image / proj_bias from lsam_mlp_block_proj_pack(attn.proj.weight [d][d], attn.proj.bias)
+ *       (lsam_mlp_block_proj_image_bytes(d) bytes, 0 = width not supported: d <= 112 only; 224 floats). */
+int lsam_window_block_attention_fwd(const float* x, void* a_out, const float* norm1_w, const float* norm1_b, const void* image,
+                                    const float* bias_table, int N, int H, int W, int nh, int hd, float eps, lsam_stream_t stream);
+size_t lsam_mlp_block_proj_image_bytes(int d);
+int lsam_mlp_block_proj_pack(const float* proj_w, const float* proj_b, int d, void* proj_image, float* proj_bias, lsam_stream_t stream);
+int lsam_mlp_block_fwd_proj(const float* x, const void* a, int lda, float* y, const float* norm2_w, const float* norm2_b,
+                            const void* image, const float* bias_table, const void* proj_image, const float* proj_bias,
+                            void* xn_next, int ldn, const float* next_norm_w, const float* next_norm_b, int M, int d, float eps,
+                            lsam_stream_t stream);
+
 /* Fused tail of a block, bf16 MFMA, in one kernel (stage-2 / stage-3 widths 224 and 448):
  *   y   = res + proj(a)                           (hieradet.py:79,163)
  *   out = y + fc2(GELU(fc1(LayerNorm2(y))))       (hieradet.py:165, MLP: sam2_utils.py:112-136)

@@ -422,6 +422,49 @@ def test_fused_mlp_block_with_next_norm(ops, d, M):
         ops.mlp_block_fwd_next_norm(x.cuda(), g2.cuda(), b2.cuda(), img, bias, gn[1:], bn)   # misaligned gamma
 
 
+@pytest.mark.parametrize("nh,hd,N,H,with_next", [(2, 56, 2, 32, True), (1, 56, 3, 16, False), (2, 32, 1, 24, True), (1, 32, 2, 8, False),
+                                                 (2, 56, 5, 40, False)])
+def test_stage1_block_split_projection(ops, nh, hd, N, H, with_next):
+    """A whole stage-1 block (hieradet.py:134-166) as the plan runs it: the attention kernel stops at its output rows and
+    proj + residual open the MLP kernel.  Against fp32 torch, and against the two kernels with the projection where it was
+    (the same products in another order: close, not bit-equal)."""
+    d = nh * hd
+    x = rnd(N, H, H, d, seed=31)
+    g1, b1 = 1 + 0.1 * rnd(d, seed=32), 0.1 * rnd(d, seed=33)
+    wqkv, bqkv = rnd(3 * d, d, seed=34) / math.sqrt(d), 0.2 * rnd(3 * d, seed=35)
+    wproj, bproj = rnd(d, d, seed=36) / math.sqrt(d), 0.2 * rnd(d, seed=37)
+    g2, b2 = 1 + 0.1 * rnd(d, seed=38), 0.1 * rnd(d, seed=39)
+    w1, c1 = rnd(4 * d, d, seed=40) / math.sqrt(d), 0.2 * rnd(4 * d, seed=41)
+    w2, c2 = rnd(d, 4 * d, seed=42) / math.sqrt(4 * d), 0.2 * rnd(d, seed=43)
+    gn, bn = 1 + 0.1 * rnd(d, seed=44), 0.1 * rnd(d, seed=45)
+    y1_ref = _win_block_ref(x, g1, b1, wqkv, bqkv, wproj, bproj, nh)
+    y_ref = y1_ref + F.gelu(F.layer_norm(y1_ref, (d,), g2, b2, 1e-6) @ w1.t() + c1) @ w2.t() + c2
+    wimg, wbias = ops.window_block_pack(wqkv.cuda(), bqkv.cuda(), wproj.cuda(), bproj.cuda(), nh)
+    mimg, mbias = ops.mlp_block_pack(w1.cuda(), c1.cuda(), w2.cuda(), c2.cuda())
+    pimg, pbias = ops.mlp_block_proj_pack(wproj.cuda(), bproj.cuda())
+    xg = x.cuda()
+    a = ops.window_block_attention_fwd(xg, g1.cuda(), b1.cuda(), wimg, wbias, nh)
+    assert a.dtype == torch.bfloat16 and a.shape == x.shape
+    out = ops.mlp_block_fwd_proj(xg.view(-1, d), a.view(-1, d), g2.cuda(), b2.cuda(), mimg, mbias, pimg, pbias,
+                                 next_norm=(gn.cuda(), bn.cuda()) if with_next else None)
+    y = out[0] if with_next else out
+    assert rel_err(y.cpu().view_as(x) - x, y_ref - x) < 1e-2
+    # the un-split pair of kernels
+    y1 = ops.window_block_fwd(xg, g1.cuda(), b1.cuda(), wimg, wbias, nh)
+    y_old = ops.mlp_block_fwd(y1.view(-1, d), g2.cuda(), b2.cuda(), mimg, mbias)
+    assert rel_err((y - xg.view(-1, d)).cpu(), (y_old - xg.view(-1, d)).cpu()) < 3e-3
+    if with_next:
+        want = F.layer_norm(y, (d,), gn.cuda(), bn.cuda(), 1e-6)
+        assert rel_err(out[1].float().cpu(), want.cpu()) < 1e-2
+    assert torch.equal(xg.cpu(), x)     # the residual stream is not written by either kernel here
+
+
+def test_stage1_block_split_projection_rejects_unsupported(ops):
+    from image_segmentation_amd._C import LsamError
+    with pytest.raises(LsamError):
+        ops.mlp_block_proj_pack(rnd(224, 224).cuda(), rnd(224).cuda())   # the W_proj fragments of a 224-wide block do not fit a chunk
+
+
 def test_fused_mlp_block_rejects_unsupported(ops):
     from image_segmentation_amd._C import LsamError
     with pytest.raises(LsamError):
