@@ -20,6 +20,9 @@ namespace lsam {
 #ifndef MLP_ABL
 #define MLP_ABL 0
 #endif
+#ifndef MLP_OPAQUE_LANE_ALL
+#define MLP_OPAQUE_LANE_ALL 0
+#endif
 #ifndef MLP_PROJ_LDS
 #define MLP_PROJ_LDS 1   // PROJ: W_proj as one more chunk of the LDS stream (1) or read from L2 as fragments (0: 595 us against 524, 36 spills)
 #endif
@@ -132,6 +135,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlpblock_kernel(cons
     const float* __restrict__ b2p = p.bias_p;
     const char* __restrict__ img = static_cast<const char*>(p.img);
 
+    constexpr bool OPQ = PROJ || MLP_OPAQUE_LANE_ALL;
     auto issue = [&](int c, int buf) {
 #if MLP_ABL & 1
         return;
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlpblock_kernel(cons
         // PROJ: the lane's byte offset is rebuilt here from an opaque lane id -- kept live across the token loop the per-piece
         // source addresses are spilled, and a scratch reload waits for vmcnt(0), i.e. for the DMA piece issued just before it
         unsigned lo = 0;
-        if constexpr (PROJ) {
+        if constexpr (OPQ) {
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
             lo *= 16;
         }
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlpblock_kernel(cons
         for (int i = 0; i < (NDMA + NW - 1) / NW; ++i) {
             const int j = wave + NW * i;
             if (j < NDMA) {
-                if constexpr (PROJ) __builtin_amdgcn_global_load_lds((mlp_gbl_p)(src + j * 1024 + lo), (mlp_lds_p)(dst + j * 1024), 16, 0, 0);
+                if constexpr (OPQ) __builtin_amdgcn_global_load_lds((mlp_gbl_p)(src + j * 1024 + lo), (mlp_lds_p)(dst + j * 1024), 16, 0, 0);
                 else __builtin_amdgcn_global_load_lds((mlp_gbl_p)(src + j * 1024 + lane * 16), (mlp_lds_p)(dst + j * 1024), 16, 0, 0);
             }
         }
@@ -169,9 +173,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mlpblock_kernel(cons
     };
     // chunk after MLP chunk c in stream order: c + 1, or the first chunk of the next token group (W_proj under PROJ)
     auto issue_next = [&](int c, int buf) {
-        if (c + 1 < nch) issue(c + 1, buf);
-        else if constexpr (PROJ && MLP_PROJ_LDS) issue_proj(buf);
-        else issue(0, buf);
+        if constexpr (PROJ && MLP_PROJ_LDS) {
+            if (c + 1 < nch) issue(c + 1, buf);
+            else issue_proj(buf);
+        } else {
+            issue(c + 1 < nch ? c + 1 : 0, buf);   // (one inlined copy of the issue loop, as before)
+        }
     };
     auto wfrag = [&](const char* base, int row, int c) -> bf16x8 {
         return *reinterpret_cast<const bf16x8*>(base + row * 128 + ((c ^ (row & 7)) << 4));
