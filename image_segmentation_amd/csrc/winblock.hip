@@ -78,9 +78,11 @@ __global__ void pack_winblock_kernel(const float* __restrict__ wqkv, const float
 #ifndef WINBLOCK_NW
 #define WINBLOCK_NW 4   // waves per workgroup (one workgroup per CU: the weight image fills the LDS)
 #endif
-template <int NH, bool ATTN_ONLY>
-__global__ __launch_bounds__(64 * WINBLOCK_NW, 1) void winblock_attn_kernel(const WinBlockArgs p) {
-    constexpr int NW = WINBLOCK_NW;
+#ifndef WINBLOCK_NW_ATTN
+#define WINBLOCK_NW_ATTN 4   // the same for the attention-only form
+#endif
+template <int NH, bool ATTN_ONLY, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void winblock_attn_kernel(const WinBlockArgs p) {
     using I = WinImg<NH>;
     constexpr int KS = 2 * NH;      // 32-wide k-steps over the model dim padded to 64 NH
     constexpr int NTO = 4 * NH;     // output column tiles of proj
@@ -397,15 +399,16 @@ int launch_pack_winblock(const float* wqkv, const float* bqkv, const float* wpro
 
 template <int NH, bool ATTN_ONLY> static int launch_wb(const WinBlockArgs& a, hipStream_t s) {
     constexpr int LDSB = WinImg<NH>::BYTES;
+    constexpr int NW = ATTN_ONLY ? WINBLOCK_NW_ATTN : WINBLOCK_NW;
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        LSAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(winblock_attn_kernel<NH, ATTN_ONLY>),
+        LSAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(winblock_attn_kernel<NH, ATTN_ONLY, NW>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
         attr_set = true;
     }
     const int nwin = a.N * (a.H / 8) * (a.W / 8);
-    const int grid = nwin / WINBLOCK_NW < 256 ? (nwin + WINBLOCK_NW - 1) / WINBLOCK_NW : 256;
-    hipLaunchKernelGGL((winblock_attn_kernel<NH, ATTN_ONLY>), dim3(grid), dim3(64 * WINBLOCK_NW), LDSB, s, a);
+    const int grid = nwin / NW < 256 ? (nwin + NW - 1) / NW : 256;
+    hipLaunchKernelGGL((winblock_attn_kernel<NH, ATTN_ONLY, NW>), dim3(grid), dim3(64 * NW), LDSB, s, a);
     LSAM_LAUNCH_CHECK();
     return LSAM_OK;
 }
